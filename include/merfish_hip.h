@@ -1,0 +1,130 @@
+/* merfish_hip.h -- C-ABI of libmerfish_hip.so (MI355X / gfx950).
+ *
+ * The reference (emanuega/MERlin v0.1.6) is pure Python and has no FFI; its
+ * extension point for this path is the PixelBasedDecoder object
+ * (merlin/util/decoding.py:25).  This header is the C boundary a maintainer
+ * binds (ctypes) beneath that object; every entry point names the reference
+ * code it replaces.  See INTEGRATION.md for the binding stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name starts with h_ (host);
+ *  - all device buffers are allocated and owned by the caller (PyTorch-ROCm
+ *    tensors' data_ptr()); the library allocates no device memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *    call only enqueues work on that stream and does not synchronise;
+ *  - return value: 0 on success, negative MF_E* code on error; the message is
+ *    available from mf_last_error_string() (thread-local);
+ *  - image volumes are [Z,H,W] row-major; "2-D mode" (conn3d = 0) treats the Z
+ *    planes as independent images, as Decode does per z-slice
+ *    (merlin/analysis/decode.py:118-127); "3-D mode" (conn3d = 1) is
+ *    decode_3d (merlin/analysis/decode.py:129-161).
+ */
+#ifndef MERFISH_HIP_H
+#define MERFISH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_OK            0
+#define MF_EINVAL       -1   /* bad argument (shape, dtype, null pointer)   */
+#define MF_EUNSUPPORTED -2   /* outside the built kernel set (B > 32, ...)  */
+#define MF_EWORKSPACE   -3   /* workspace too small                         */
+#define MF_EHIP         -4   /* a HIP runtime call failed                   */
+
+#define MF_MAX_BITS     32   /* bits per codeword supported by the kernels  */
+#define MF_MAX_RADIUS    4   /* blur radius: ksize <= 9, i.e. sigma <= 2    */
+#define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
+
+#define MF_DTYPE_U16     0
+#define MF_DTYPE_F32     1
+#define MF_DTYPE_F64     2
+
+int mf_version(void);
+const char *mf_last_error_string(void);
+
+/* cv2.GaussianBlur kernel taps (merlin/util/decoding.py:94-97): the 16.16
+ * fixed-point taps OpenCV 4.x uses for CV_16U (sum == 65536) and the float32
+ * taps used for float input.  Host-only helper; h_fixed / h_float hold ksize
+ * entries each. */
+int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed,
+                     float *h_float);
+
+/* decode_pixels (merlin/util/decoding.py:46-131) for Z planes at once.
+ *
+ *   image      u16 (MF_DTYPE_U16) or f32 stack, element (b,z,y,x) at
+ *              image[b*img_bit_stride + z*img_z_stride + y*W + x]
+ *   codebook   f64 [N,B] L2-normalised rows (_calculate_normalized_barcodes,
+ *              decoding.py:254-276)
+ *   h_scale, h_background   host float[B]: scale factors / backgrounds already
+ *              rounded to float32 (legacy numpy value casting, decoding.py:103)
+ *   decoded    int16 [Z,H,W]   barcode index or -1
+ *   magnitudes f32   [Z,H,W]
+ *   distances  f32 or f64 [Z,H,W] (dist_dtype), NOT masked by the thresholds
+ *   traces     f32, element (z,b,y,x) at traces[z*tr_z_stride+b*tr_bit_stride
+ *              + y*W + x]; may be NULL (fused path: traces not materialised)
+ *
+ * Blur: ksize = 2*ceil(2*sigma)+1 <= 9, BORDER_REFLECT_101, exact integer
+ * arithmetic for u16.  Nearest codeword: exact float64 Euclidean 1-NN (lowest
+ * index on exact ties), replacing sklearn NearestNeighbors (decoding.py:112). */
+int mf_decode_pixels(const void *image, int image_dtype,
+                     int B, int Z, int H, int W,
+                     int64_t img_bit_stride, int64_t img_z_stride,
+                     const double *codebook, int N,
+                     const float *h_scale, const float *h_background,
+                     double sigma, double distance_threshold,
+                     float magnitude_threshold,
+                     int16_t *decoded, float *magnitudes,
+                     void *distances, int dist_dtype,
+                     float *traces, int64_t tr_z_stride, int64_t tr_bit_stride,
+                     void *stream);
+
+/* Connected-component labelling of the decoded image: replaces the N calls to
+ * skimage.measure.label(decodedImage == i) (decoding.py:165-166, 324-325,
+ * 360-361) by one multi-label pass.  Two pixels are connected iff they hold
+ * the same barcode index >= 0 and are 8-neighbours (conn3d = 0, each z plane
+ * on its own) or 26-neighbours (conn3d = 1).
+ *
+ *   labels  int32 [Z,H,W]: linear index (z*H*W + y*W + x) of the first pixel
+ *           of the component in raster order; -1 for unassigned pixels
+ *   counts  int64 [2] (device): counts[0] = assigned pixels, counts[1] =
+ *           components.  The caller reads it back to size the tables below. */
+int mf_label_components(const int16_t *decoded, int Z, int H, int W,
+                        int conn3d, int32_t *labels, int64_t *counts,
+                        void *stream);
+
+/* Bytes of scratch mf_region_table needs for the given sizes. */
+int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
+                                  int64_t n_regions);
+
+/* regionprops-style aggregation (decoding.py:165-241, 323-334, 359-369) of
+ * every component at once.  Rows are ordered as the reference emits them:
+ * z plane (2-D mode only), then barcode index, then skimage label order
+ * (raster order of the first pixel).
+ *
+ *   rec      f64 [n_regions, MF_REC_COLS]:
+ *            0 barcode_id  1 z plane (2-D mode) / first-pixel z (3-D mode)
+ *            2 area        3 mean_intensity      4 max_intensity
+ *            5 mean_distance  6 min_distance
+ *            7 centroid z  8 centroid row (y)    9 centroid column (x)
+ *            10 first-pixel linear index         11 reserved (0)
+ *   inten    f32 [n_regions, B]  per-bit mean of the normalised traces
+ *   mean_tm  f32 [n_regions, B]  per-bit mean of trace*magnitude, or NULL
+ *   min_tm   f32 [n_regions, B]  per-bit min  of trace*magnitude, or NULL
+ *            (extract_refactors / _extract_backgrounds inputs; 2-D mode)
+ *   n_pixels / n_regions: the counts mf_label_components produced. */
+int mf_region_table(const int16_t *decoded, const float *magnitudes,
+                    const void *distances, int dist_dtype,
+                    const float *traces, int64_t tr_z_stride,
+                    int64_t tr_bit_stride, const int32_t *labels,
+                    int B, int Z, int H, int W, int conn3d,
+                    int64_t n_pixels, int64_t n_regions,
+                    double *rec, float *inten, float *mean_tm, float *min_tm,
+                    void *workspace, int64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERFISH_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libmerfish_hip.so (the C-ABI in include/merfish_hip.h).
+
+The library is the product path; there is no CPU fallback.  Importing this
+module never touches the GPU; ``lib()`` loads the shared object and raises a
+RuntimeError naming the build command when it is missing.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmerfish_hip.so')
+
+MF_DTYPE_U16 = 0
+MF_DTYPE_F32 = 1
+MF_DTYPE_F64 = 2
+MF_MAX_BITS = 32
+MF_MAX_RADIUS = 4
+MF_REC_COLS = 12
+
+# every symbol include/merfish_hip.h declares
+EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
+           'mf_decode_pixels', 'mf_label_components',
+           'mf_region_workspace_bytes', 'mf_region_table')
+
+_lib = None
+
+
+class MerfishHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MerfishHipError(
+            'libmerfish_hip.so is not built ({}). Build it with '
+            '`python -m merlin_amd._build` (needs hipcc); there is no CPU '
+            'fallback.'.format(LIB_PATH))
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i32, i64, f64, f32 = c.c_void_p, c.c_int, c.c_int64, c.c_double, c.c_float
+    L.mf_version.restype = i32
+    L.mf_version.argtypes = []
+    L.mf_last_error_string.restype = c.c_char_p
+    L.mf_last_error_string.argtypes = []
+    L.mf_gaussian_taps.restype = i32
+    L.mf_gaussian_taps.argtypes = [i32, f64, c.POINTER(c.c_uint32),
+                                   c.POINTER(c.c_float)]
+    L.mf_decode_pixels.restype = i32
+    L.mf_decode_pixels.argtypes = [
+        vp, i32, i32, i32, i32, i32, i64, i64, vp, i32,
+        c.POINTER(c.c_float), c.POINTER(c.c_float), f64, f64, f32,
+        vp, vp, vp, i32, vp, i64, i64, vp]
+    L.mf_label_components.restype = i32
+    L.mf_label_components.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    L.mf_region_workspace_bytes.restype = i64
+    L.mf_region_workspace_bytes.argtypes = [i32, i32, i32, i64, i64]
+    L.mf_region_table.restype = i32
+    L.mf_region_table.argtypes = [
+        vp, vp, vp, i32, vp, i64, i64, vp, i32, i32, i32, i32, i32, i64, i64,
+        vp, vp, vp, vp, vp, i64, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        msg = lib().mf_last_error_string().decode('utf-8', 'replace')
+        if rc == -2:
+            raise NotImplementedError('libmerfish_hip: ' + msg)
+        if rc == -1:
+            raise ValueError('libmerfish_hip: ' + msg)
+        raise MerfishHipError('libmerfish_hip error {}: {}'.format(rc, msg))
+    return rc
+
+
+def gaussian_taps(ksize, sigma):
+    """(fixed-point taps uint32[ksize], float taps float32[ksize])."""
+    import numpy as np
+    fx = (ctypes.c_uint32 * ksize)()
+    fl = (ctypes.c_float * ksize)()
+    check(lib().mf_gaussian_taps(int(ksize), float(sigma), fx, fl))
+    return np.array(fx[:], dtype=np.uint32), np.array(fl[:], dtype=np.float32)

@@ -1,0 +1,374 @@
+// regions.hip -- connected-component labelling of the decoded image and
+// regionprops-style aggregation, for gfx950 (MI355X).
+//
+// Replaces the per-barcode skimage.measure.label + regionprops loops of
+// merlin/util/decoding.py:165-241 (extract_barcodes_with_index), :323-334
+// (extract_refactors) and :359-369 (_extract_backgrounds): ONE multi-label
+// union-find pass labels every barcode's regions at once, and one segmented
+// pass over the assigned pixels (a few % of the image) produces every region
+// row.  All of it is HBM-bound integer work on sparse data; nothing here is
+// shaped like a GEMM.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ CCL ---
+
+__device__ __forceinline__ int ld_label(const int32_t *L, int i)
+{
+    // agent-scope load: parents are updated by atomics from other XCDs
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int find_root(const int32_t *L, int x)
+{
+    int p = ld_label(L, x);
+    while (p != x) { x = p; p = ld_label(L, x); }
+    return x;
+}
+
+// Union by smallest index: the root of a component is always its first pixel
+// in raster order, which is what orders skimage's labels.
+__device__ __forceinline__ void unite(int32_t *L, int a, int b)
+{
+    for (;;) {
+        a = find_root(L, a);
+        b = find_root(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(L + a, b);
+        if (old == a) return;
+        a = old;            // a was linked meanwhile: keep uniting its parent
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+ccl_init(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int n)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < n) L[i] = dec[i] >= 0 ? i : -1;
+}
+
+__global__ void __launch_bounds__(NT)
+ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int Z, int H, int W, int conn3d)
+{
+    const int n = Z * H * W;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const int16_t code = dec[i];
+    if (code < 0) return;
+    const int x = i % W;
+    const int y = (i / W) % H;
+    const int z = i / (W * H);
+    // same plane: W, NW, N, NE
+    if (x > 0 && dec[i - 1] == code) unite(L, i, i - 1);
+    if (y > 0) {
+        if (x > 0 && dec[i - W - 1] == code) unite(L, i, i - W - 1);
+        if (dec[i - W] == code) unite(L, i, i - W);
+        if (x + 1 < W && dec[i - W + 1] == code) unite(L, i, i - W + 1);
+    }
+    if (conn3d && z > 0) {
+        const int base = i - W * H;
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (y + dy < 0 || y + dy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (x + dx < 0 || x + dx >= W) continue;
+                const int q = base + dy * W + dx;
+                if (dec[q] == code) unite(L, i, q);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NT)
+ccl_flatten(int32_t *L, int n, unsigned long long *counts)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    int fg = 0, root = 0;
+    if (i < n) {
+        const int p = L[i];
+        if (p >= 0) {
+            int r = p;
+            int q = L[r];
+            while (q != r) { r = q; q = L[r]; }
+            L[i] = r;
+            fg = 1;
+            root = r == i;
+        }
+    }
+    // one atomic per wave
+    const unsigned long long mf_ = __ballot(fg), mr_ = __ballot(root);
+    if ((threadIdx.x & 63) == 0) {
+        if (mf_) atomicAdd(counts + 0, (unsigned long long)__popcll(mf_));
+        if (mr_) atomicAdd(counts + 1, (unsigned long long)__popcll(mr_));
+    }
+}
+
+// --------------------------------------------------------- region table ---
+
+struct IsAssigned {
+    const int32_t *L;
+    __device__ bool operator()(int i) const { return L[i] >= 0; }
+};
+
+struct IsBoundary {
+    const uint64_t *k;
+    __device__ bool operator()(int i) const { return i == 0 || k[i] != k[i - 1]; }
+};
+
+// key = ((plane-or-0) * 32768 + barcode) << root_bits | root
+__global__ void __launch_bounds__(NT)
+make_keys(const int32_t *__restrict__ pix, const int16_t *__restrict__ dec,
+          const int32_t *__restrict__ L, int64_t n, int plane_px, int conn3d, int root_bits,
+          uint64_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix[i];
+    const uint64_t root = (uint64_t)L[p];
+    const uint64_t grp = conn3d ? 0u : (uint64_t)(p / plane_px);
+    keys[i] = ((grp * 32768u + (uint64_t)dec[p]) << root_bits) | root;
+}
+
+struct StatsArgs {
+    const int32_t *pix;      // sorted by (group, barcode, root), raster order inside
+    const int32_t *offsets;  // [n_regions]
+    int64_t n_pix, n_reg;
+    const int16_t *dec;
+    const float *mag;
+    const void *dist;
+    int dist_f64;
+    const float *traces;
+    int64_t tr_z, tr_b;
+    int B, Z, H, W, conn3d;
+    double *rec;
+    float *inten, *mean_tm, *min_tm;
+};
+
+__global__ void __launch_bounds__(NT)
+region_stats(const StatsArgs a)
+{
+    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (r >= a.n_reg) return;
+    const int64_t i0 = a.offsets[r];
+    const int64_t i1 = r + 1 < a.n_reg ? a.offsets[r + 1] : a.n_pix;
+    const int n = (int)(i1 - i0);
+    const int plane = a.H * a.W;
+    const int first = a.pix[i0];
+
+    // pass 1: magnitude sum / max, distance sum / min
+    double msum = 0.0, dsum = 0.0, dmin = INFINITY;
+    float mmax = -INFINITY;
+    for (int64_t i = i0; i < i1; ++i) {
+        const int p = a.pix[i];
+        const float m = a.mag[p];
+        msum += (double)m;
+        mmax = fmaxf(mmax, m);
+        const double d = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[p]
+                                    : (double)reinterpret_cast<const float *>(a.dist)[p];
+        dsum += d;
+        dmin = fmin(dmin, d);
+    }
+    // pass 2: magnitude-weighted centroid
+    double cz, cy, cx;
+    if (n == 1) {
+        cz = first / plane; cy = (first % plane) / a.W; cx = first % a.W;
+    } else {
+        cz = cy = cx = 0.0;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int p = a.pix[i];
+            const double w = (double)a.mag[p] / msum;
+            cz += (double)(p / plane) * w;
+            cy += (double)((p % plane) / a.W) * w;
+            cx += (double)(p % a.W) * w;
+        }
+    }
+    double mean_int = msum / n, mean_d = n > 1 ? dsum / n : dsum;
+    if (a.conn3d) mean_int = (double)(float)mean_int;        // regionprops: f32
+    if (a.conn3d && !a.dist_f64) mean_d = (double)(float)mean_d;
+    if (!a.conn3d) cz = first / plane;
+
+    double *row = a.rec + r * MF_REC_COLS;
+    row[0] = (double)a.dec[first];
+    row[1] = (double)(first / plane);
+    row[2] = (double)n;
+    row[3] = mean_int;
+    row[4] = (double)mmax;
+    row[5] = mean_d;
+    row[6] = dmin;
+    row[7] = cz;
+    row[8] = cy;
+    row[9] = cx;
+    row[10] = (double)first;
+    row[11] = 0.0;
+
+    // per-bit means: sequential float32 sums in raster order, then / n
+    // (np.mean(list of f32 rows, axis 0), decoding.py:197, 220, 330)
+    for (int b = 0; b < a.B; ++b) {
+        float s = 0.0f, stm = 0.0f, mn = INFINITY;
+        for (int64_t i = i0; i < i1; ++i) {
+            const int p = a.pix[i];
+            const int zz = p / plane;
+            const float t = a.traces[(int64_t)zz * a.tr_z + (int64_t)b * a.tr_b + (p - zz * plane)];
+            s = s + t;
+            if (a.mean_tm || a.min_tm) {
+                const float tm = t * a.mag[p];
+                stm = stm + tm;
+                mn = fminf(mn, tm);
+            }
+        }
+        a.inten[r * a.B + b] = n > 1 ? s / (float)n : s;
+        if (a.mean_tm) a.mean_tm[r * a.B + b] = stm / (float)n;
+        if (a.min_tm) a.min_tm[r * a.B + b] = mn;
+    }
+}
+
+// workspace carve-up shared by the size query and the call
+struct Plan {
+    size_t keys_a, keys_b, pix_a, pix_b, offsets, count, temp, temp_bytes, total;
+    int root_bits, key_bits;
+};
+
+inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+
+int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
+{
+    const int64_t vol = (int64_t)Z * H * W;
+    int rb = 1;
+    while (((int64_t)1 << rb) < vol) ++rb;
+    pl.root_bits = rb;
+    int gb = 15;                       // barcode < 32768
+    int zb = 0;
+    while ((1 << zb) < Z) ++zb;
+    pl.key_bits = rb + gb + zb;
+    if (pl.key_bits > 64) return mf::fail(MF_EUNSUPPORTED, "sort key needs %d bits", pl.key_bits);
+
+    const size_t np = (size_t)(n_pix > 0 ? n_pix : 1), nr = (size_t)(n_reg > 0 ? n_reg : 1);
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    // size queries (null temp storage): no work is enqueued
+    hipError_t e;
+    e = rocprim::select(nullptr, t1, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
+                        (unsigned long long *)nullptr, (size_t)vol, IsAssigned{nullptr});
+    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
+    e = rocprim::radix_sort_pairs(nullptr, t2, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                  (int32_t *)nullptr, (int32_t *)nullptr, np, 0u,
+                                  (unsigned)pl.key_bits);
+    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
+    e = rocprim::select(nullptr, t3, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
+                        (unsigned long long *)nullptr, np, IsBoundary{nullptr});
+    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
+    pl.temp_bytes = t1 > t2 ? t1 : t2;
+    if (t3 > pl.temp_bytes) pl.temp_bytes = t3;
+
+    size_t off = 0;
+    pl.keys_a = off; off += align_up(np * 8);
+    pl.keys_b = off; off += align_up(np * 8);
+    pl.pix_a = off; off += align_up(np * 4);
+    pl.pix_b = off; off += align_up(np * 4);
+    pl.offsets = off; off += align_up((nr + 1) * 4);
+    pl.count = off; off += 256;
+    pl.temp = off; off += align_up(pl.temp_bytes);
+    pl.total = off;
+    return MF_OK;
+}
+
+}  // namespace
+
+extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, int conn3d,
+                                   int32_t *labels, int64_t *counts, void *stream)
+{
+    if (!decoded || !labels || !counts) return mf::fail(MF_EINVAL, "null pointer argument");
+    if (Z < 1 || H < 1 || W < 1) return mf::fail(MF_EINVAL, "bad shape Z=%d H=%d W=%d", Z, H, W);
+    const int64_t vol = (int64_t)Z * H * W;
+    if (vol > INT32_MAX) return mf::fail(MF_EUNSUPPORTED, "volume exceeds 2^31 pixels");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int n = (int)vol;
+    const unsigned grid = (unsigned)((n + NT - 1) / NT);
+    MF_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), s));
+    hipLaunchKernelGGL(ccl_init, dim3(grid), dim3(NT), 0, s, decoded, labels, n);
+    hipLaunchKernelGGL(ccl_merge, dim3(grid), dim3(NT), 0, s, decoded, labels, Z, H, W, conn3d);
+    hipLaunchKernelGGL(ccl_flatten, dim3(grid), dim3(NT), 0, s, labels, n,
+                       reinterpret_cast<unsigned long long *>(counts));
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
+extern "C" int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
+                                             int64_t n_regions)
+{
+    Plan pl;
+    const int rc = make_plan(Z, H, W, n_pixels, n_regions, pl);
+    if (rc) return rc;
+    return (int64_t)pl.total;
+}
+
+extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
+                               const void *distances, int dist_dtype, const float *traces,
+                               int64_t tr_z_stride, int64_t tr_bit_stride,
+                               const int32_t *labels, int B, int Z, int H, int W, int conn3d,
+                               int64_t n_pixels, int64_t n_regions, double *rec, float *inten,
+                               float *mean_tm, float *min_tm, void *workspace,
+                               int64_t workspace_bytes, void *stream)
+{
+    if (n_regions == 0 || n_pixels == 0) return MF_OK;
+    if (!decoded || !magnitudes || !distances || !traces || !labels || !rec || !inten || !workspace)
+        return mf::fail(MF_EINVAL, "null pointer argument");
+    if (B < 1 || Z < 1 || H < 1 || W < 1 || n_pixels < n_regions || n_regions < 0)
+        return mf::fail(MF_EINVAL, "bad sizes");
+    if (dist_dtype != MF_DTYPE_F32 && dist_dtype != MF_DTYPE_F64)
+        return mf::fail(MF_EINVAL, "distance dtype %d not f32/f64", dist_dtype);
+    const int64_t vol = (int64_t)Z * H * W;
+    if (vol > INT32_MAX || n_pixels > vol) return mf::fail(MF_EINVAL, "bad pixel count");
+    Plan pl;
+    int rc = make_plan(Z, H, W, n_pixels, n_regions, pl);
+    if (rc) return rc;
+    if ((int64_t)pl.total > workspace_bytes)
+        return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes", (long long)workspace_bytes,
+                        (long long)pl.total);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    uint64_t *keys_a = reinterpret_cast<uint64_t *>(ws + pl.keys_a);
+    uint64_t *keys_b = reinterpret_cast<uint64_t *>(ws + pl.keys_b);
+    int32_t *pix_a = reinterpret_cast<int32_t *>(ws + pl.pix_a);
+    int32_t *pix_b = reinterpret_cast<int32_t *>(ws + pl.pix_b);
+    int32_t *offsets = reinterpret_cast<int32_t *>(ws + pl.offsets);
+    unsigned long long *count = reinterpret_cast<unsigned long long *>(ws + pl.count);
+    void *temp = ws + pl.temp;
+    size_t tb = pl.temp_bytes;
+
+    // 1. assigned pixels in raster order
+    MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), pix_a, count,
+                                 (size_t)vol, IsAssigned{labels}, s));
+    // 2. (plane, barcode, root) keys; stable sort keeps raster order per region
+    const unsigned gp = (unsigned)((n_pixels + NT - 1) / NT);
+    hipLaunchKernelGGL(make_keys, dim3(gp), dim3(NT), 0, s, pix_a, decoded, labels, n_pixels,
+                       H * W, conn3d, pl.root_bits, keys_a);
+    tb = pl.temp_bytes;
+    MF_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys_a, keys_b, pix_a, pix_b,
+                                           (size_t)n_pixels, 0u, (unsigned)pl.key_bits, s));
+    // 3. region starts
+    tb = pl.temp_bytes;
+    MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), offsets, count,
+                                 (size_t)n_pixels, IsBoundary{keys_b}, s));
+    // 4. per-region rows
+    StatsArgs a;
+    a.pix = pix_b; a.offsets = offsets; a.n_pix = n_pixels; a.n_reg = n_regions;
+    a.dec = decoded; a.mag = magnitudes; a.dist = distances;
+    a.dist_f64 = dist_dtype == MF_DTYPE_F64;
+    a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride;
+    a.B = B; a.Z = Z; a.H = H; a.W = W; a.conn3d = conn3d;
+    a.rec = rec; a.inten = inten; a.mean_tm = mean_tm; a.min_tm = min_tm;
+    const unsigned gr = (unsigned)((n_regions + NT - 1) / NT);
+    hipLaunchKernelGGL(region_stats, dim3(gr), dim3(NT), 0, s, a);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}

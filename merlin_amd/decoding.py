@@ -1,0 +1,486 @@
+"""MI355X drop-in for ``merlin.util.decoding`` (reference: merlin/util/decoding.py).
+
+``PixelBasedDecoder`` keeps the reference's constructor, method names,
+argument meaning, return tuple and error behaviour (decoding.py:25-377), so
+``merlin.analysis.decode.Decode`` and ``optimize.OptimizeIteration`` can use
+it unchanged.  All arithmetic runs in the HIP kernels of libmerfish_hip.so;
+this module only moves tensors, caches device-resident results and assembles
+the pandas tables.  There is no CPU fallback: without the library or a GPU the
+calls raise.
+
+Beyond the reference API the class offers device-resident variants
+(``decode_pixels_device``, ``extract_barcodes``) that the FOV runner in
+``merlin_amd.decode`` uses to keep a whole field of view on the GPU.
+"""
+import weakref
+from typing import Optional, Tuple
+
+import numpy as np
+import pandas
+import torch
+
+from merlin_amd import _lib
+
+COLUMN_NAMES = ['barcode_id', 'fov', 'mean_intensity', 'max_intensity',
+                'area', 'mean_distance', 'min_distance', 'x', 'y', 'z',
+                'global_x', 'global_y', 'global_z', 'cell_index']
+
+
+def normalize(x):
+    """decoding.py:17-22"""
+    norm = np.linalg.norm(x)
+    if norm > 0:
+        return x / norm
+    else:
+        return x
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class DecodedVolume(object):
+    """Device-resident output of one decode call: Z planes of one FOV.
+
+    decoded int16 [Z,H,W], magnitudes f32 [Z,H,W], distances f32|f64 [Z,H,W],
+    traces f32 [Z,B,H,W] (or None when not materialised)."""
+
+    def __init__(self, decoded, magnitudes, distances, traces, bit_count):
+        self.decoded = decoded
+        self.magnitudes = magnitudes
+        self.distances = distances
+        self.traces = traces
+        self.bit_count = bit_count
+        self._tables = {}
+
+    @property
+    def shape(self):
+        return tuple(self.decoded.shape)
+
+
+class RegionTable(object):
+    """Host copy of mf_region_table's output, rows in reference order."""
+
+    def __init__(self, rec, inten, mean_tm=None, min_tm=None):
+        self.rec = rec
+        self.inten = inten
+        self.mean_tm = mean_tm
+        self.min_tm = min_tm
+
+    def __len__(self):
+        return self.rec.shape[0]
+
+
+class PixelBasedDecoder(object):
+
+    def __init__(self, codebook, scaleFactors: np.ndarray = None,
+                 backgrounds: np.ndarray = None, device=None):
+        self._codebook = codebook
+        self._decodingMatrix = self._calculate_normalized_barcodes()
+        self._barcodeCount = self._decodingMatrix.shape[0]
+        self._bitCount = self._decodingMatrix.shape[1]
+
+        if scaleFactors is None:
+            self._scaleFactors = np.ones(self._decodingMatrix.shape[1])
+        else:
+            self._scaleFactors = scaleFactors.copy()
+
+        if backgrounds is None:
+            self._backgrounds = np.zeros(self._decodingMatrix.shape[1])
+        else:
+            self._backgrounds = backgrounds.copy()
+
+        self.refactorAreaThreshold = 4
+
+        if self._bitCount > _lib.MF_MAX_BITS:
+            raise NotImplementedError(
+                'codebooks with more than {} bits are not supported'.format(
+                    _lib.MF_MAX_BITS))
+        self._device = torch.device(device) if device is not None else None
+        self._cb_dev = None
+        self._recent = []       # [(weakrefs of returned arrays, DecodedVolume)]
+
+    # ------------------------------------------------------------ helpers --
+
+    def _calculate_normalized_barcodes(self, ignoreBlanks=False):
+        """decoding.py:254-276 (the includeErrors branch is never used)."""
+        barcodeSet = np.asarray(
+            self._codebook.get_barcodes(ignoreBlanks=ignoreBlanks))
+        return np.array([normalize(x) for x in barcodeSet], dtype=np.float64)
+
+    def _dev(self):
+        if self._device is None:
+            if not torch.cuda.is_available():
+                raise _lib.MerfishHipError(
+                    'no GPU visible: merlin_amd has no CPU fallback')
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        return self._device
+
+    def _codebook_device(self):
+        if self._cb_dev is None:
+            self._cb_dev = torch.from_numpy(
+                np.ascontiguousarray(self._decodingMatrix)).to(self._dev())
+        return self._cb_dev
+
+    @staticmethod
+    def _f32_params(values, count, name):
+        v = np.asarray(values, dtype=np.float64).reshape(-1)
+        if v.shape[0] != count:
+            raise ValueError('{} must have one entry per bit ({} != {})'
+                             .format(name, v.shape[0], count))
+        # legacy numpy value casting keeps (p - b) / s in float32
+        return np.ascontiguousarray(v.astype(np.float32))
+
+    # -------------------------------------------------------- decode_pixels --
+
+    def decode_pixels_device(self, imageData: torch.Tensor,
+                             scaleFactors=None, backgrounds=None,
+                             distanceThreshold: float = 0.5176,
+                             magnitudeThreshold: float = 1,
+                             lowPassSigma: float = 1,
+                             returnTraces: bool = True,
+                             distanceDtype=torch.float64) -> DecodedVolume:
+        """decode_pixels on a device-resident stack.
+
+        imageData: uint16 / float32 tensor [B,H,W] or [B,Z,H,W] on the GPU
+        (the layout preprocess.get_processed_image_set returns,
+        preprocess.py:79-93).  Returns a DecodedVolume (tensors stay on the
+        GPU)."""
+        L = _lib.lib()
+        dev = self._dev()
+        if scaleFactors is None:
+            scaleFactors = self._scaleFactors
+        if backgrounds is None:
+            backgrounds = self._backgrounds
+        if imageData.dim() == 3:
+            imageData = imageData.unsqueeze(1)
+        if imageData.dim() != 4:
+            raise ValueError('imageData must be [B,H,W] or [B,Z,H,W]')
+        B, Z, H, W = imageData.shape
+        if B != self._bitCount:
+            raise ValueError('image stack has {} bits, codebook {}'.format(
+                B, self._bitCount))
+        if imageData.dtype == torch.uint16:
+            dt = _lib.MF_DTYPE_U16
+        elif imageData.dtype == torch.float32:
+            dt = _lib.MF_DTYPE_F32
+        else:
+            raise TypeError('imageData must be uint16 or float32, got {}'
+                            .format(imageData.dtype))
+        if imageData.device != dev:
+            imageData = imageData.to(dev)
+        if imageData.stride(3) != 1 or imageData.stride(2) != W:
+            imageData = imageData.contiguous()
+        sf = self._f32_params(scaleFactors, B, 'scaleFactors')
+        bg = self._f32_params(backgrounds, B, 'backgrounds')
+
+        with torch.cuda.device(dev):
+            decoded = torch.empty((Z, H, W), dtype=torch.int16, device=dev)
+            mags = torch.empty((Z, H, W), dtype=torch.float32, device=dev)
+            dist = torch.empty((Z, H, W), dtype=distanceDtype, device=dev)
+            traces = torch.empty((Z, B, H, W), dtype=torch.float32,
+                                 device=dev) if returnTraces else None
+            ddt = _lib.MF_DTYPE_F64 if distanceDtype == torch.float64 \
+                else _lib.MF_DTYPE_F32
+            cb = self._codebook_device()
+            import ctypes
+            fp = ctypes.POINTER(ctypes.c_float)
+            _lib.check(L.mf_decode_pixels(
+                imageData.data_ptr(), dt, B, Z, H, W,
+                imageData.stride(0), imageData.stride(1),
+                cb.data_ptr(), self._barcodeCount,
+                sf.ctypes.data_as(fp), bg.ctypes.data_as(fp),
+                float(lowPassSigma), float(distanceThreshold),
+                float(np.float32(magnitudeThreshold)),
+                decoded.data_ptr(), mags.data_ptr(), dist.data_ptr(), ddt,
+                _ptr(traces), B * H * W if returnTraces else 0,
+                H * W if returnTraces else 0, _stream_ptr(dev)))
+        # keep the input alive until the stream has consumed it
+        imageData.record_stream(torch.cuda.current_stream(dev))
+        return DecodedVolume(decoded, mags, dist, traces, B)
+
+    def decode_pixels(self, imageData: np.ndarray,
+                      scaleFactors: np.ndarray = None,
+                      backgrounds: np.ndarray = None,
+                      distanceThreshold: float = 0.5176,
+                      magnitudeThreshold: float = 1,
+                      lowPassSigma: float = 1):
+        """Assign barcodes to the pixels in the provided image stack.
+
+        Same contract as decoding.py:46-131: imageData [B,H,W]; returns
+        (decodedImage int16 [H,W], pixelMagnitudes float32 [H,W],
+        normalizedPixelTraces float32 [B,H,W], distances float64 [H,W]) as
+        numpy arrays.  uint16 input takes the integer blur cv2 applies to
+        CV_16U; any other dtype is blurred as float32."""
+        if isinstance(imageData, torch.Tensor):
+            img = imageData
+        else:
+            arr = np.asarray(imageData)
+            if arr.ndim != 3:
+                raise ValueError('imageData must be [bits, H, W]')
+            if arr.dtype != np.uint16:
+                arr = arr.astype(np.float32)
+            img = torch.from_numpy(np.ascontiguousarray(arr))
+        vol = self.decode_pixels_device(
+            img.to(self._dev()), scaleFactors, backgrounds, distanceThreshold,
+            magnitudeThreshold, lowPassSigma, True, torch.float64)
+        decoded = vol.decoded[0].cpu().numpy()
+        mags = vol.magnitudes[0].cpu().numpy()
+        traces = vol.traces[0].cpu().numpy()
+        dist = vol.distances[0].cpu().numpy()
+        self._remember((decoded, mags, traces, dist), vol)
+        return decoded, mags, traces, dist
+
+    # ------------------------------------------------ device result caching --
+
+    def _remember(self, arrays, vol):
+        refs = tuple(weakref.ref(a) for a in arrays)
+        self._recent.append((refs, vol))
+        del self._recent[:-4]
+
+    def _lookup(self, decodedImage, pixelMagnitudes, pixelTraces, distances):
+        """DecodedVolume for arrays this decoder returned earlier (matched by
+        identity), else upload the given arrays."""
+        for refs, vol in reversed(self._recent):
+            d, m, t, ds = (r() for r in refs)
+            if d is decodedImage and m is pixelMagnitudes \
+                    and t is pixelTraces \
+                    and (distances is None or ds is distances):
+                return vol
+        dev = self._dev()
+        dec = np.ascontiguousarray(decodedImage, dtype=np.int16)
+        is3d = np.asarray(pixelTraces).ndim == 4
+        if not is3d:
+            dec = dec[None]
+        def up(a, dt=None):
+            a = np.ascontiguousarray(a) if dt is None \
+                else np.ascontiguousarray(a, dtype=dt)
+            return torch.from_numpy(a).to(dev)
+        mags = up(pixelMagnitudes, np.float32)
+        tr = up(pixelTraces, np.float32)
+        if distances is None:
+            dist = None
+        else:
+            darr = np.asarray(distances)
+            dist = up(darr, np.float32 if darr.dtype == np.float32
+                      else np.float64)
+        if not is3d:
+            mags, tr = mags[None], tr[None]
+            dist = None if dist is None else dist[None]
+        vol = DecodedVolume(torch.from_numpy(dec).to(dev), mags, dist, tr,
+                            tr.shape[1])
+        keep = (decodedImage, pixelMagnitudes, pixelTraces,
+                distances if distances is not None else pixelMagnitudes)
+        if all(isinstance(a, np.ndarray) for a in keep):
+            self._remember(keep, vol)
+        return vol
+
+    # --------------------------------------------------------- region table --
+
+    def region_table(self, vol: DecodedVolume, is3D: bool = False,
+                     withRefactorStats: bool = False) -> RegionTable:
+        """CCL + region aggregation of every barcode at once on the GPU
+        (replaces the per-index label/regionprops loop, decoding.py:165-221,
+        323-334, 359-369).  Cached on the DecodedVolume."""
+        key = (bool(is3D), bool(withRefactorStats))
+        if key in vol._tables:
+            return vol._tables[key]
+        if (bool(is3D), True) in vol._tables:
+            return vol._tables[(bool(is3D), True)]
+        if vol.traces is None:
+            raise ValueError('region extraction needs the pixel traces')
+        L = _lib.lib()
+        dev = vol.decoded.device
+        Z, H, W = vol.shape
+        B = vol.bit_count
+        with torch.cuda.device(dev):
+            sp = _stream_ptr(dev)
+            labels = torch.empty((Z, H, W), dtype=torch.int32, device=dev)
+            counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            _lib.check(L.mf_label_components(
+                vol.decoded.data_ptr(), Z, H, W, int(is3D),
+                labels.data_ptr(), counts.data_ptr(), sp))
+            n_pix, n_reg = (int(v) for v in counts.cpu())
+            rec = torch.empty((n_reg, _lib.MF_REC_COLS), dtype=torch.float64,
+                              device=dev)
+            inten = torch.empty((n_reg, B), dtype=torch.float32, device=dev)
+            mean_tm = min_tm = None
+            if withRefactorStats:
+                mean_tm = torch.empty((n_reg, B), dtype=torch.float32,
+                                      device=dev)
+                min_tm = torch.empty((n_reg, B), dtype=torch.float32,
+                                     device=dev)
+            if n_reg > 0:
+                ws_bytes = _lib.check(L.mf_region_workspace_bytes(
+                    Z, H, W, n_pix, n_reg))
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                dist = vol.distances if vol.distances is not None \
+                    else vol.magnitudes
+                ddt = _lib.MF_DTYPE_F64 if dist.dtype == torch.float64 \
+                    else _lib.MF_DTYPE_F32
+                tr = vol.traces
+                _lib.check(L.mf_region_table(
+                    vol.decoded.data_ptr(), vol.magnitudes.data_ptr(),
+                    dist.data_ptr(), ddt, tr.data_ptr(), tr.stride(0),
+                    tr.stride(1), labels.data_ptr(), B, Z, H, W, int(is3D),
+                    n_pix, n_reg, rec.data_ptr(), inten.data_ptr(),
+                    _ptr(mean_tm), _ptr(min_tm), ws.data_ptr(), ws_bytes, sp))
+            table = RegionTable(
+                rec.cpu().numpy(), inten.cpu().numpy(),
+                None if mean_tm is None else mean_tm.cpu().numpy(),
+                None if min_tm is None else min_tm.cpu().numpy())
+        vol._tables[key] = table
+        vol.labels = labels
+        return table
+
+    # ------------------------------------------ extract_barcodes_with_index --
+
+    def _frame_from_rows(self, table: RegionTable, rows, is3D, bitCount,
+                         fov, cropWidth, zIndex, globalAligner, minimumArea,
+                         cropShape) -> pandas.DataFrame:
+        """Assemble the reference's DataFrame (decoding.py:171-252) for the
+        given region rows."""
+        intensityColumns = ['intensity_{}'.format(i) for i in range(bitCount)]
+        rec = table.rec[rows]
+        n = rec.shape[0]
+        if n == 0:
+            return pandas.DataFrame(columns=COLUMN_NAMES + intensityColumns)
+
+        centroids = np.zeros((n, 3))
+        # reference order: [z, x (column), y (row)] (decoding.py:188, 209-211)
+        if is3D:
+            centroids[:, 0] = rec[:, 7]
+        else:
+            centroids[:, 0] = zIndex if zIndex is not None else np.nan
+        centroids[:, 1] = rec[:, 9]
+        centroids[:, 2] = rec[:, 8]
+        if globalAligner is not None:
+            globalCentroids = globalAligner.fov_coordinate_array_to_global(
+                fov, centroids)
+        else:
+            globalCentroids = centroids
+
+        df = pandas.DataFrame(np.zeros((n, len(COLUMN_NAMES))),
+                              columns=COLUMN_NAMES)
+        df['barcode_id'] = rec[:, 0].astype(np.int64)
+        df['fov'] = fov
+        df[['mean_intensity', 'max_intensity', 'area']] = rec[:, [3, 4, 2]]
+        df[['mean_distance', 'min_distance']] = rec[:, [5, 6]]
+        df[['x', 'y', 'z']] = centroids[:, [1, 2, 0]]
+        df[['global_x', 'global_y', 'global_z']] = \
+            np.asarray(globalCentroids)[:, [1, 2, 0]]
+        df['cell_index'] = -1
+        intensities = pandas.DataFrame(table.inten[rows],
+                                       columns=intensityColumns)
+        fullDF = pandas.concat([df, intensities], axis=1)
+        # exclusive crop on the centroid, quirks included: x is compared with
+        # shape[0] and y with shape[1] of the decoded image (decoding.py:244)
+        keep = ((fullDF['x'] > cropWidth)
+                & (fullDF['x'] < cropShape[0] - cropWidth)
+                & (fullDF['y'] > cropWidth)
+                & (fullDF['y'] < cropShape[1] - cropWidth)
+                & (fullDF['area'] >= minimumArea))
+        return fullDF[keep]
+
+    def extract_barcodes_with_index(
+            self, barcodeIndex: int, decodedImage: np.ndarray,
+            pixelMagnitudes: np.ndarray, pixelTraces: np.ndarray,
+            distances: np.ndarray, fov: int, cropWidth: int,
+            zIndex: int = None, globalAligner=None, minimumArea: int = 0
+    ) -> pandas.DataFrame:
+        """Same contract as decoding.py:133-252.  The first call for a set of
+        images labels and aggregates every barcode on the GPU; later calls
+        with the same arrays slice the cached table."""
+        is3D = len(pixelTraces.shape) == 4
+        vol = self._lookup(decodedImage, pixelMagnitudes, pixelTraces,
+                           distances)
+        table = self.region_table(vol, is3D)
+        ids = table.rec[:, 0]
+        rows = np.nonzero(ids == barcodeIndex)[0]
+        bitCount = pixelTraces.shape[1] if is3D else pixelTraces.shape[0]
+        return self._frame_from_rows(
+            table, rows, is3D, bitCount, fov, cropWidth, zIndex,
+            globalAligner, minimumArea, decodedImage.shape)
+
+    def extract_barcodes(self, vol: DecodedVolume, fov: int, cropWidth: int,
+                         zIndex=None, globalAligner=None,
+                         minimumArea: int = 0, is3D: bool = False,
+                         zPlane: Optional[int] = None) -> pandas.DataFrame:
+        """All barcode indexes at once = pandas.concat over
+        extract_barcodes_with_index(i, ...) for i in range(N)
+        (analysis/decode.py:225-230), from a device-resident volume.
+        In 2-D mode ``zPlane`` selects one plane of a multi-plane volume."""
+        table = self.region_table(vol, is3D)
+        if is3D or zPlane is None:
+            rows = np.arange(len(table))
+        else:
+            rows = np.nonzero(table.rec[:, 1] == zPlane)[0]
+        Z, H, W = vol.shape
+        cropShape = (Z, H, W) if is3D else (H, W)
+        return self._frame_from_rows(
+            table, rows, is3D, vol.bit_count, fov, cropWidth, zIndex,
+            globalAligner, minimumArea, cropShape)
+
+    # ---------------------------------------------------- extract_refactors --
+
+    def _refactors_from_table(self, table: RegionTable, rows,
+                              extractBackgrounds: bool):
+        N, B = self._barcodeCount, self._bitCount
+        ids = table.rec[rows, 0].astype(np.int64)
+        area = table.rec[rows, 2]
+        if extractBackgrounds:
+            # decoding.py:342-377, area threshold 5 hard-coded at :362
+            sel = area >= 5
+            seenBg = np.bincount(ids[sel], minlength=N).astype(np.float64)
+            sumMin = np.zeros((N, B))
+            np.add.at(sumMin, ids[sel],
+                      table.min_tm[rows][sel].astype(np.float64))
+            off = sumMin.copy()
+            off[self._decodingMatrix > 0] = np.nan
+            with np.errstate(invalid='ignore', divide='ignore'):
+                backgroundRefactors = np.nansum(off, axis=0) / np.sum(
+                    (self._decodingMatrix == 0) * seenBg[:, np.newaxis],
+                    axis=0)
+        else:
+            backgroundRefactors = np.zeros(B)
+
+        sel = area >= self.refactorAreaThreshold
+        barcodesSeen = np.bincount(ids[sel], minlength=N).astype(np.float64)
+        mean = table.mean_tm[rows][sel].astype(np.float64) \
+            - backgroundRefactors
+        with np.errstate(invalid='ignore', divide='ignore'):
+            norm = np.array([np.linalg.norm(v) for v in mean]) \
+                if len(mean) else np.zeros(0)
+            contrib = (mean / norm[:, None]) / barcodesSeen[ids[sel]][:, None]
+        sumPixelTraces = np.zeros((N, B))
+        np.add.at(sumPixelTraces, ids[sel], contrib)   # region order per code
+        sumPixelTraces[self._decodingMatrix == 0] = np.nan
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', category=RuntimeWarning)
+            onBitIntensity = np.nanmean(sumPixelTraces, axis=0)
+            refactors = onBitIntensity / np.mean(onBitIntensity)
+        return refactors, backgroundRefactors, barcodesSeen
+
+    def extract_refactors(
+            self, decodedImage, pixelMagnitudes, normalizedPixelTraces,
+            extractBackgrounds=False
+    ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Same contract as decoding.py:290-340: (refactors[B],
+        backgroundRefactors[B], barcodesSeen[N])."""
+        vol = self._lookup(decodedImage, pixelMagnitudes,
+                           normalizedPixelTraces, None)
+        table = self.region_table(vol, False, True)
+        return self._refactors_from_table(table, np.arange(len(table)),
+                                          extractBackgrounds)
+
+    def extract_refactors_device(self, vol: DecodedVolume,
+                                 extractBackgrounds=False, zPlane=None):
+        table = self.region_table(vol, False, True)
+        rows = np.arange(len(table)) if zPlane is None \
+            else np.nonzero(table.rec[:, 1] == zPlane)[0]
+        return self._refactors_from_table(table, rows, extractBackgrounds)

@@ -1,0 +1,148 @@
+"""GPU: the HIP path, called through the C-ABI (via the PixelBasedDecoder
+drop-in), against the oracle and the reference-generated golden vectors.
+
+Bar: decoded indexes, connected components, areas and every integer column are
+bit-exact; float32 magnitudes/traces and float64 distances are bit-exact
+against the oracle (same operation order) and within float32 rounding of the
+reference goldens (whose norm goes through BLAS); record floats within 1e-12
+relative of the oracle's float64 sums (summation order) and 1e-6 for float32
+means."""
+import warnings
+
+import numpy as np
+import pytest
+
+import merfish_oracle as oracle
+from conftest import (ArrayCodebook, AffineAligner, frame_to_array,
+                      golden_names, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder(g, gpu_device):
+    from merlin_amd.decoding import PixelBasedDecoder
+    dec = PixelBasedDecoder(ArrayCodebook(g['codebook']), device=gpu_device)
+    dec.refactorAreaThreshold = g['p']['refactor_area']
+    return dec
+
+
+def _decode_gpu(dec, g):
+    p = g['p']
+    img = g['image']
+    if not p['decode3d']:
+        return dec.decode_pixels(img, g['sf'], g['bg'], p['dthr'], p['mthr'],
+                                 p['sigma'])
+    outs = [dec.decode_pixels(img[:, z], g['sf'], g['bg'], p['dthr'],
+                              p['mthr'], p['sigma'])
+            for z in range(img.shape[1])]
+    return (np.array([o[0] for o in outs]), np.array([o[1] for o in outs]),
+            np.array([o[2] for o in outs]),
+            np.array([o[3] for o in outs]).astype(np.float32))
+
+
+def _decode_oracle(g):
+    p = g['p']
+    dm = oracle.normalized_codebook(g['codebook'])
+    img = g['image']
+    if not p['decode3d']:
+        return oracle.decode_pixels(img, dm, g['sf'], g['bg'], p['dthr'],
+                                    p['mthr'], p['sigma'])
+    outs = [oracle.decode_pixels(img[:, z], dm, g['sf'], g['bg'], p['dthr'],
+                                 p['mthr'], p['sigma'])
+            for z in range(img.shape[1])]
+    return (np.array([o[0] for o in outs]), np.array([o[1] for o in outs]),
+            np.array([o[2] for o in outs]),
+            np.array([o[3] for o in outs]).astype(np.float32))
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_decode_pixels_golden(name, gpu_device):
+    g = load_golden(name)
+    dec = _decoder(g, gpu_device)
+    di, pm, npt, d = _decode_gpu(dec, g)
+    assert di.dtype == np.int16 and pm.dtype == np.float32
+    assert npt.dtype == np.float32
+    # vs the reference's own output
+    assert np.array_equal(di, g['decoded'])
+    np.testing.assert_allclose(pm, g['magnitudes'], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(npt, g['traces'], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(d, g['distances'], rtol=1e-6, atol=2e-7)
+    # vs the oracle: same operation order, so bit-exact
+    odi, opm, onpt, od = _decode_oracle(g)
+    assert np.array_equal(di, odi)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(d, od)
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_extract_barcodes_golden(name, gpu_device):
+    """extract_barcodes_with_index over every index on the GOLDEN images
+    (uploaded as numpy arrays, as the Decode task passes them)."""
+    g = load_golden(name)
+    p = g['p']
+    N, B = g['codebook'].shape
+    dec = _decoder(g, gpu_device)
+    al = AffineAligner(g['tform']) if 'tform' in g else None
+    frames = [dec.extract_barcodes_with_index(
+        i, g['decoded'], g['magnitudes'], g['traces'], g['distances'],
+        p['fov'], p['crop'], p['z_index'], al, p['min_area'])
+        for i in range(N)]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        import pandas
+        r = frame_to_array(pandas.concat(frames), B)
+    exp = g['records']
+    assert r.shape == exp.shape
+    # integer-valued columns: barcode_id, fov, area, cell_index
+    for c in (0, 1, 4, 13):
+        assert np.array_equal(r[:, c], exp[:, c])
+    # max_intensity, min_distance are selections: exact
+    assert np.array_equal(r[:, 3], exp[:, 3])
+    assert np.array_equal(r[:, 6], exp[:, 6])
+    np.testing.assert_allclose(r[:, :14], exp[:, :14], rtol=1e-6, atol=1e-6)
+    if p['decode3d']:
+        np.testing.assert_allclose(r[:, 14:], exp[:, 14:], rtol=1e-6, atol=1e-7)
+    else:
+        # 2-D: float64 sums differ from numpy's pairwise order by rounding
+        np.testing.assert_allclose(r[:, :14], exp[:, :14], rtol=1e-12, atol=1e-12)
+        # per-bit float32 means: same sequential order => bit-exact
+        assert np.array_equal(r[:, 14:], exp[:, 14:])
+    # empty index gives the reference's empty frame
+    if len(exp) < N:
+        empty = [f for f in frames if len(f) == 0][0]
+        assert list(empty.columns)[:3] == ['barcode_id', 'fov', 'mean_intensity']
+        assert len(empty.columns) == 14 + B
+
+
+@pytest.mark.parametrize('name', [n for n in golden_names()
+                                  if 'decode3d' not in n])
+def test_extract_refactors_golden(name, gpu_device):
+    g = load_golden(name)
+    dec = _decoder(g, gpu_device)
+    rf, bgr, seen = dec.extract_refactors(
+        g['decoded'], g['magnitudes'], g['traces'], False)
+    assert np.array_equal(seen, g['barcodes_seen'])
+    np.testing.assert_allclose(rf, g['refactors'], rtol=1e-12, equal_nan=True)
+    assert np.array_equal(bgr, np.zeros(g['codebook'].shape[1]))
+    if 'refactors_bg' in g:
+        rf, bgr, seen = dec.extract_refactors(
+            g['decoded'], g['magnitudes'], g['traces'], True)
+        np.testing.assert_allclose(rf, g['refactors_bg'], rtol=1e-12,
+                                   equal_nan=True)
+        np.testing.assert_allclose(bgr, g['background_refactors'],
+                                   rtol=1e-12, equal_nan=True)
+
+
+def test_cached_device_path_equals_upload_path(gpu_device):
+    """decode_pixels -> extract (device-cached) == extract on re-uploaded
+    copies of the same arrays."""
+    g = load_golden('g2_synth192')
+    p = g['p']
+    dec = _decoder(g, gpu_device)
+    di, pm, npt, d = _decode_gpu(dec, g)
+    a = dec.extract_barcodes_with_index(5, di, pm, npt, d, 0, 0, 0)
+    dec2 = _decoder(g, gpu_device)
+    b = dec2.extract_barcodes_with_index(5, di.copy(), pm.copy(), npt.copy(),
+                                         d.copy(), 0, 0, 0)
+    assert a.equals(b)
