@@ -1,0 +1,194 @@
+"""bench.py -- decoded Mpixels/s for the pixel-decode hot path on MI355X.
+
+One "step" = one full field of view (BASELINE.json configs[1]: 2048x2048,
+7 z-planes, 16-bit MHD4 codebook with 140 codewords) taken from a uint16 stack
+already resident in HBM to the barcode table on the host:
+decode_pixels for every plane (one launch) -> connected components -> region
+table -> D2H of the records -> the reference's DataFrame.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+With N ranks every rank decodes its own FOVs (FOVs are independent units,
+analysis/decode.py:71-72): weak scaling, no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Z, H, W, B = 7, 2048, 2048, 16
+SPOTS_PER_PLANE = 40000
+SEED = 1234
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def load_codebook():
+    from merlin_amd.codebook import Codebook
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', 'testsuite_inputs.npz'))
+    return Codebook(d['codebook'])
+
+
+def initial_scale_factors(img):
+    """optimize.py:140-155 on the device: argmin|cdf - 0.9| + 2 per bit."""
+    out = np.zeros(img.shape[0])
+    for b in range(img.shape[0]):
+        h = torch.bincount(img[b].reshape(-1).to(torch.int32),
+                           minlength=65535)[:65534].double()
+        c = torch.cumsum(h, 0)
+        c = c / c[-1]
+        out[b] = float(torch.argmin(torch.abs(c - 0.9))) + 2
+    return out
+
+
+def cpu_baseline(codebook, img_plane, sf, bg, params):
+    """The oracle (numpy port of the reference algorithm) timed on one
+    1024x1024 plane of the same workload, single core."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import warnings
+    import merfish_oracle as oracle
+    dm = oracle.normalized_codebook(codebook.get_barcodes())
+    t0 = time.perf_counter()
+    di, pm, npt, d = oracle.decode_pixels(
+        img_plane, dm, sf, bg, params['distance_threshold'], 1,
+        params['lowpass_sigma'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        oracle.extract_all_barcodes(
+            dm.shape[0], di, pm, npt, d, 0, params['crop_width'], 0, None,
+            params['minimum_area'])
+    dt = time.perf_counter() - t0
+    px = img_plane.shape[1] * img_plane.shape[2]
+    return {'value': px / dt / 1e6, 'unit': 'Mpx/s', 'cores': 1,
+            'kind': 'port',
+            'sample': 'one 1024x1024 plane x 16 bits of the same synthetic '
+                      'FOV: oracle decode_pixels + 140x extract_barcodes '
+                      '({:.1f} s)'.format(dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from merlin_amd.decode import Decode
+    from merlin_amd.synthetic import synthetic_fov
+
+    codebook = load_codebook()
+    params = {'crop_width': 100, 'distance_threshold': 0.5167,
+              'lowpass_sigma': 1, 'minimum_area': 0}
+    task = Decode(codebook, params, device=dev)
+
+    # two distinct FOVs per rank, alternated, so no step sees a warm cache of
+    # its own previous outputs
+    fovs = [synthetic_fov(codebook.get_barcodes(), Z, H, W, SPOTS_PER_PLANE,
+                          SEED + 2 * rank + i, dev) for i in range(2)]
+    sf = initial_scale_factors(fovs[0])
+    bg = np.zeros(B)
+
+    def step(i):
+        bc, vol = task.run_fov(fovs[i % 2], sf, bg, fov=i)
+        return bc, vol
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        bc, vol = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        bc, vol = step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_records = len(bc)
+    n_decoded = int((vol.decoded >= 0).sum())
+    del bc, vol
+
+    # ---- roofline of the dominant kernel (decode_kernel), HIP events on the
+    # stream the library launches on (torch's current stream) ----
+    px_fov = Z * H * W
+    reps = 10
+    for _ in range(2):
+        v = task.decode_fov_device(fovs[0], sf, bg)
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    outs = task.decoder  # noqa
+    e0.record()
+    for r in range(reps):
+        v = task.decode_fov_device(fovs[r % 2], sf, bg)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    k_ms = e0.elapsed_time(e1) / reps
+    # algorithmic bytes per pixel: 2B in (u16 stack) + 2 (int16 id) + 4
+    # (magnitude) + 8 (float64 distance) + 4B (normalised traces) = 6B + 14
+    alg_bytes = px_fov * (6 * B + 14)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    del v
+
+    if rank == 0:
+        mpx = world * args.steps * px_fov / dt / 1e6
+        out = {
+            'metric': 'decoded_Mpixels_per_sec',
+            'value': mpx, 'unit': 'Mpx/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u16/f32/f64',
+            'data': 'synthetic',
+            'fovs_per_sec': world * args.steps / dt,
+            'config': {
+                'workload': 'single FOV 2048x2048x7 z-planes, 16-bit MHD4 '
+                            'codebook (140 codewords), u16 stack resident in '
+                            'HBM -> barcode DataFrame on host',
+                'bits': B, 'z': Z, 'h': H, 'w': W, 'codewords': 140,
+                'spots_per_plane': SPOTS_PER_PLANE,
+                'records_per_fov': n_records, 'decoded_px_per_fov': n_decoded,
+                'parallelism': 'fov-sharded x{}'.format(world)},
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'decode_kernel<u16,R=2,B<=16>',
+                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'kernel_ms': k_ms, 'algorithmic_bytes': alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            plane = fovs[0][:, 0, :1024, :1024].cpu().numpy()
+            out['cpu_baseline'] = cpu_baseline(codebook, plane, sf, bg,
+                                               task.parameters)
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

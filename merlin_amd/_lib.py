@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmerfish_hip.so')
+# MERFISH_HIP_LIB: development override to time kernel variants
+LIB_PATH = os.environ.get('MERFISH_HIP_LIB') or os.path.join(
+    _HERE, 'libmerfish_hip.so')
 
 MF_DTYPE_U16 = 0
 MF_DTYPE_F32 = 1

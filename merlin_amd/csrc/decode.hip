@@ -27,7 +27,10 @@ namespace {
 
 constexpr int TW = 64;              // tile width  = wave width
 constexpr int NTHREADS = 256;       // 4 waves
-constexpr float TIE_EPS = 1.0e-5f;  // score gap below which float64 decides
+#ifndef MF_TIE_EPS
+#define MF_TIE_EPS 1.0e-5f
+#endif
+constexpr float TIE_EPS = MF_TIE_EPS;  // score gap below which float64 decides
 
 struct DecodeArgs {
     const void *img;
@@ -347,6 +350,10 @@ int dispatch_bits(DecodeArgs &a, hipStream_t s)
 template <typename PIX>
 int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
 {
+#ifdef MF_DEV_BUILD   // development: only the sigma=1 kernels, quick compile
+    if (R == 2) return dispatch_bits<PIX, 2>(a, s);
+    return mf::fail(MF_EUNSUPPORTED, "dev build: R=2 only");
+#endif
     switch (R) {
     case 0: return dispatch_bits<PIX, 0>(a, s);
     case 1: return dispatch_bits<PIX, 1>(a, s);

@@ -1,0 +1,81 @@
+"""FOV-level decode runner: the MI355X counterpart of
+merlin/analysis/decode.py::Decode._run_analysis (decode.py:92-175).
+
+The reference task pulls images through MERlin's dataset/task framework (out
+of scope); this runner takes the same inputs as tensors and returns
+the same products: the barcode table the task writes to the barcode database
+(decode.py:225-230) and the decoded / magnitude / distance images
+(decode.py:113-127).  Parameter names and defaults are the task's
+(decode.py:46-66)."""
+from typing import Optional
+
+import numpy as np
+import pandas
+import torch
+
+from merlin_amd.decoding import PixelBasedDecoder, DecodedVolume
+
+
+class Decode(object):
+
+    def __init__(self, codebook, parameters=None, device=None):
+        self.parameters = dict(parameters or {})
+        p = self.parameters
+        p.setdefault('crop_width', 100)
+        p.setdefault('write_decoded_images', True)
+        p.setdefault('minimum_area', 0)
+        p.setdefault('distance_threshold', 0.5167)
+        p.setdefault('lowpass_sigma', 1)
+        p.setdefault('decode_3d', False)
+        p.setdefault('memory_map', False)
+        p.setdefault('remove_z_duplicated_barcodes', False)
+        if p['remove_z_duplicated_barcodes']:
+            p.setdefault('z_duplicate_zPlane_threshold', 1)
+            p.setdefault('z_duplicate_xy_pixel_threshold', np.sqrt(2))
+        self.cropWidth = p['crop_width']
+        self._codebook = codebook
+        self.decoder = PixelBasedDecoder(codebook, device=device)
+
+    def get_codebook(self):
+        return self._codebook
+
+    def decode_fov_device(self, imageStack: torch.Tensor, scaleFactors,
+                          backgrounds) -> DecodedVolume:
+        """Blur + normalise + nearest codeword for every z plane of one FOV
+        in one launch.  imageStack: uint16 [B,Z,H,W] on the GPU."""
+        p = self.parameters
+        return self.decoder.decode_pixels_device(
+            imageStack, scaleFactors, backgrounds,
+            distanceThreshold=p['distance_threshold'],
+            lowPassSigma=p['lowpass_sigma'], returnTraces=True,
+            distanceDtype=torch.float32 if p['decode_3d'] else torch.float64)
+
+    def run_fov(self, imageStack: torch.Tensor, scaleFactors, backgrounds,
+                fov: int, globalAligner=None, zPositions=None):
+        """decode.py:92-175 for one FOV.  Returns (barcodes DataFrame,
+        DecodedVolume); the volume's decoded/magnitudes/distances tensors are
+        the images _save_decoded_images would write."""
+        p = self.parameters
+        vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
+        Z = vol.shape[0]
+        if p['decode_3d']:
+            bc = self.decoder.extract_barcodes(
+                vol, fov, self.cropWidth, None, globalAligner,
+                p['minimum_area'], is3D=True)
+        else:
+            frames = []
+            table = self.decoder.region_table(vol, False)
+            for z in range(Z):
+                rows = np.nonzero(table.rec[:, 1] == z)[0]
+                frames.append(self.decoder._frame_from_rows(
+                    table, rows, False, vol.bit_count, fov, self.cropWidth,
+                    z, globalAligner, p['minimum_area'], vol.shape[1:]))
+            bc = pandas.concat(frames) if frames else pandas.DataFrame()
+        if p['remove_z_duplicated_barcodes']:
+            from merlin_amd import barcodefilters
+            zpos = zPositions if zPositions is not None \
+                else list(range(Z))
+            bc = barcodefilters.remove_zplane_duplicates_all_barcodeids(
+                bc, p['z_duplicate_zPlane_threshold'],
+                p['z_duplicate_xy_pixel_threshold'], zpos)
+        return bc, vol
