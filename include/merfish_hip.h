@@ -52,12 +52,25 @@ const char *mf_last_error_string(void);
 int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed,
                      float *h_float);
 
+/* Codebook table (replaces PixelBasedDecoder.__init__ /
+ * _calculate_normalized_barcodes' float64 matrix, decoding.py:27-44, 254-276,
+ * as the device-side form the kernels read).
+ *
+ *   h_codebook  HOST f64 [N,B]: L2-normalised rows exactly as the reference
+ *               builds them.  MERFISH codewords are binary, so every non-zero
+ *               entry of a row must carry the same value; anything else
+ *               returns MF_EUNSUPPORTED.
+ *   table       device buffer of mf_codebook_table_bytes(N, B) bytes
+ * Synchronous (one hipMemcpy); call once per codebook. */
+int64_t mf_codebook_table_bytes(int N, int B);
+int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
+                        int64_t table_bytes);
+
 /* decode_pixels (merlin/util/decoding.py:46-131) for Z planes at once.
  *
  *   image      u16 (MF_DTYPE_U16) or f32 stack, element (b,z,y,x) at
  *              image[b*img_bit_stride + z*img_z_stride + y*W + x]
- *   codebook   f64 [N,B] L2-normalised rows (_calculate_normalized_barcodes,
- *              decoding.py:254-276)
+ *   codebook_table  device table from mf_codebook_prepare for N codewords
  *   h_scale, h_background   host float[B]: scale factors / backgrounds already
  *              rounded to float32 (legacy numpy value casting, decoding.py:103)
  *   decoded    int16 [Z,H,W]   barcode index or -1
@@ -67,12 +80,16 @@ int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed,
  *              + y*W + x]; may be NULL (fused path: traces not materialised)
  *
  * Blur: ksize = 2*ceil(2*sigma)+1 <= 9, BORDER_REFLECT_101, exact integer
- * arithmetic for u16.  Nearest codeword: exact float64 Euclidean 1-NN (lowest
- * index on exact ties), replacing sklearn NearestNeighbors (decoding.py:112). */
+ * arithmetic for u16.  Nearest codeword replaces sklearn NearestNeighbors
+ * (decoding.py:112-116): the winner is the exact float64 Euclidean 1-NN
+ * (lowest index on exact ties) for every pixel that can pass the distance
+ * threshold; for a pixel farther than the threshold whose two best float32
+ * scores differ by < 1e-5 the reported winner may be either of them, so its
+ * distance agrees with the exact one to ~1e-6 relative. */
 int mf_decode_pixels(const void *image, int image_dtype,
                      int B, int Z, int H, int W,
                      int64_t img_bit_stride, int64_t img_z_stride,
-                     const double *codebook, int N,
+                     const void *codebook_table, int N,
                      const float *h_scale, const float *h_background,
                      double sigma, double distance_threshold,
                      float magnitude_threshold,

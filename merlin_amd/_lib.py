@@ -21,6 +21,7 @@ MF_REC_COLS = 12
 
 # every symbol include/merfish_hip.h declares
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
+           'mf_codebook_table_bytes', 'mf_codebook_prepare',
            'mf_decode_pixels', 'mf_label_components',
            'mf_region_workspace_bytes', 'mf_region_table')
 
@@ -50,6 +51,10 @@ def lib():
     L.mf_gaussian_taps.restype = i32
     L.mf_gaussian_taps.argtypes = [i32, f64, c.POINTER(c.c_uint32),
                                    c.POINTER(c.c_float)]
+    L.mf_codebook_table_bytes.restype = i64
+    L.mf_codebook_table_bytes.argtypes = [i32, i32]
+    L.mf_codebook_prepare.restype = i32
+    L.mf_codebook_prepare.argtypes = [c.POINTER(c.c_double), i32, i32, vp, i64]
     L.mf_decode_pixels.restype = i32
     L.mf_decode_pixels.argtypes = [
         vp, i32, i32, i32, i32, i32, i64, i64, vp, i32,

@@ -4,15 +4,29 @@
 // Replaces merlin/util/decoding.py:93-129 (decode_pixels) for Z planes at once.
 //
 // One workgroup (256 threads = 4 waves) owns a 64 x (4*PPT) pixel tile; lane =
-// column, every thread carries PPT vertically adjacent pixels so that each
-// wave-level load/store is one contiguous row segment.  Per bit the tile (+halo)
-// is staged through LDS, blurred separably with exact integer arithmetic, and
-// the scaled value lands in a per-thread register array x[PPT][MAXB]; the stack
-// is read from HBM exactly once and the traces are written (optionally) once.
-// The normalised codebook sits in LDS as float32 rows that every lane reads at
-// the same address (broadcast), each lane keeps a running (best, second,
-// argbest) over codewords for its own pixels, and only near-ties are re-scored
-// in float64, so the winner equals the exact float64 1-NN of the reference.
+// column and every thread carries PPT vertically adjacent pixels, so each
+// wave-level store is one contiguous row segment.
+//
+//  * Low-pass: bits are staged four at a time.  Every thread pulls 16-byte
+//    windows of the u16 rows straight from global memory (prefetched into
+//    registers one group ahead), does the horizontal pass in registers with
+//    exact u32 arithmetic and parks the u32 row sums in LDS; after one barrier
+//    each thread reads its column of row sums back and finishes the vertical
+//    pass with two exact 32-bit sums (the 48-bit total is split into 16-bit
+//    halves).  The stack is read from HBM once.
+//  * Scale / background / magnitude / normalise stay in registers
+//    (x[PPT][MAXB]), in numpy's float32 operation order.
+//  * Nearest codeword: MERFISH codebooks are binary, so the score of codeword n
+//    is v_n * sum_{on bits} x_b - |c_n|^2/2.  The sum over on-bits is a
+//    [codewords x bits] x [bits x pixels] product with a 0/1 matrix: it runs on
+//    the matrix cores (v_mfma_f32_32x32x16_bf16) with x split exactly into
+//    three bf16 terms, so the products are exact and only the float32
+//    accumulation rounds.  Each lane keeps a running (best, second, argbest)
+//    over its accumulator registers; the two lanes that share a pixel merge
+//    through v_permlane32_swap.  The winner's distance is recomputed in
+//    float64 exactly as the reference does, and a pixel whose top two scores
+//    are closer than TIE_EPS is re-decided by an exact float64 scan whenever it
+//    could pass the distance threshold.
 //
 // Built with -ffp-contract=off: every float op below is the single IEEE
 // operation it is written as; fused multiply-adds are explicit fmaf() calls.
@@ -21,22 +35,38 @@
 #include <cstdint>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 
 namespace {
 
 constexpr int TW = 64;              // tile width  = wave width
 constexpr int NTHREADS = 256;       // 4 waves
+constexpr int GROUP = 4;            // bits staged per barrier pair
 #ifndef MF_TIE_EPS
 #define MF_TIE_EPS 1.0e-5f
 #endif
-constexpr float TIE_EPS = MF_TIE_EPS;  // score gap below which float64 decides
+constexpr float TIE_EPS = MF_TIE_EPS;   // score gap below which float64 decides
+constexpr double TIE_D2_MARGIN = 1.0e-4;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Device codebook table built by mf_codebook_prepare (offsets in bytes from
+// the start of the blob, 256-byte aligned; a function of N and B only).
+struct CbHeader {
+    int32_t magic, N, B, Npad, KB, uniform, pad0, pad1;
+    int64_t off_a, off_mask, off_v, off_hn, off_v64, off_cb64, total;
+};
+constexpr int32_t CB_MAGIC = 0x4d464342;   // "MFCB"
 
 struct DecodeArgs {
     const void *img;
     int64_t bit_stride, z_stride;
-    int B, Z, H, W, N;
-    const double *cb64;
+    int B, Z, H, W, N, Npad, fast_ok;
+    const unsigned char *cbt;          // codebook table blob
+    int64_t off_a, off_mask, off_v, off_hn, off_v64;
     float sf[MF_MAX_BITS], bg[MF_MAX_BITS];
     uint32_t kfix[2 * MF_MAX_RADIUS + 1];
     float kflt[2 * MF_MAX_RADIUS + 1];
@@ -50,7 +80,7 @@ struct DecodeArgs {
     int64_t tr_z, tr_b;
     int tiles_x, tiles_y;
     int n_tiles;
-    int chunk;        // codewords per LDS chunk
+    int chunk;        // codewords per LDS chunk (multiple of 32)
 };
 
 __device__ __forceinline__ int reflect101(int i, int n)
@@ -60,51 +90,87 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-// 0.5 * |c_n|^2 and the float32 row, computed identically wherever needed
-__device__ __forceinline__ float half_norm(const double *row, int B)
-{
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) s += row[b] * row[b];
-    return (float)(0.5 * s);
-}
-
 template <typename PIX> struct HType { using type = uint32_t; };
 template <> struct HType<float> { using type = float; };
 
+struct Top2 {
+    float best, second;
+    int bi;
+};
+
+__device__ __forceinline__ void top2_update(Top2 &t, float s, int n)
+{
+    t.second = __builtin_amdgcn_fmed3f(t.best, t.second, s);
+    t.bi = s > t.best ? n : t.bi;
+    t.best = fmaxf(t.best, s);
+}
+
+// exact float64 squared distance between the normalised trace and codeword
+// (mask, v): sum_b (x_b - c_b)^2 in bit order (sklearn's rdist loop)
+template <int MAXB>
+__device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask, double v, int B)
+{
+    double d2 = 0.0;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+        if (b < B) {
+            const double c = (mask >> b) & 1u ? v : 0.0;
+            const double t = (double)x[b] - c;
+            d2 = d2 + t * t;
+        }
+    return d2;
+}
+
 template <typename PIX, int R, int MAXB, int PPT>
-__global__ void __launch_bounds__(NTHREADS)
+__global__ void __launch_bounds__(NTHREADS, 2)
 decode_kernel(const DecodeArgs a)
 {
     using HT = typename HType<PIX>::type;
+    constexpr bool IS_U16 = std::is_same<PIX, uint16_t>::value;
     constexpr int TH = 4 * PPT;
-    constexpr int RH = TH + 2 * R;
-    constexpr int RW = TW + 2 * R;
-    constexpr int K = 2 * R + 1;
-    constexpr size_t RAW_BYTES = ((size_t)RH * RW * sizeof(PIX) + 15) & ~size_t(15);
-    constexpr size_t HS_BYTES = (size_t)RH * TW * sizeof(HT);
+    constexpr int RH = TH + 2 * R;                 // rows staged per bit
+    constexpr int RA = (R + 1) & ~1;               // radius rounded up to even
+    constexpr int NW = 4 + 2 * RA;                 // window elements per task
+    constexpr int WDW = NW * (int)sizeof(PIX) / 4; // window dwords
+    constexpr int TASKS = GROUP * RH * 16;         // 4-output row pieces per group
+    constexpr int NTASK = (TASKS + NTHREADS - 1) / NTHREADS;
+    constexpr int NG = MAXB / GROUP;
+    constexpr int KS = MAXB / 16;                  // MFMA k-steps
+    constexpr size_t HS_BYTES = (size_t)GROUP * RH * TW * sizeof(HT);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PIX *raw = reinterpret_cast<PIX *>(smem);
-    HT *hs = reinterpret_cast<HT *>(smem + RAW_BYTES);
-    float *cb = reinterpret_cast<float *>(smem + RAW_BYTES + HS_BYTES);  // [chunk][MAXB]
-    float *hn = cb + (size_t)a.chunk * MAXB;                             // [chunk]
+    HT *hs = reinterpret_cast<HT *>(smem);                           // [GROUP][RH][TW]
+    unsigned char *lds_a = smem + HS_BYTES;                          // bf16 [chunk][MAXB]
+    float *lds_v = reinterpret_cast<float *>(lds_a + (size_t)a.chunk * MAXB * 2);
+    float *lds_hn = lds_v + a.chunk;
+    float *lds_sf = lds_hn + a.chunk;                                // [MAXB] scale factors
+    float *lds_bg = lds_sf + MAXB;                                   // [MAXB] backgrounds
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int B = a.B, H = a.H, W = a.W, N = a.N;
-    const bool single_chunk = a.chunk >= N;
+    const int half = lane >> 5;
+    const int B = a.B, H = a.H, W = a.W;
+    const bool single_chunk = a.chunk >= a.Npad;
     const PIX *img = reinterpret_cast<const PIX *>(a.img);
+    const uint32_t *g_mask = reinterpret_cast<const uint32_t *>(a.cbt + a.off_mask);
+    const double *g_v64 = reinterpret_cast<const double *>(a.cbt + a.off_v64);
+    const int uniform = reinterpret_cast<const CbHeader *>(a.cbt)->uniform;
 
-    auto load_chunk = [&](int c0, int cn) {
-        for (int i = tid; i < cn * MAXB; i += NTHREADS) {
-            const int n = i / MAXB, b = i - n * MAXB;
-            cb[i] = b < B ? (float)a.cb64[(size_t)(c0 + n) * B + b] : 0.0f;
-        }
-        for (int n = tid; n < cn; n += NTHREADS)
-            hn[n] = half_norm(a.cb64 + (size_t)(c0 + n) * B, B);
+    auto load_chunk = [&](int c0, int cn) {   // cn multiple of 32
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.cbt + a.off_a + (size_t)c0 * MAXB * 2);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(lds_a);
+        for (int i = tid; i < cn * MAXB * 2 / 16; i += NTHREADS) dst[i] = src[i];
+        const float *sv = reinterpret_cast<const float *>(a.cbt + a.off_v) + c0;
+        const float *sh = reinterpret_cast<const float *>(a.cbt + a.off_hn) + c0;
+        for (int i = tid; i < cn; i += NTHREADS) { lds_v[i] = sv[i]; lds_hn[i] = sh[i]; }
     };
-    if (single_chunk) load_chunk(0, N);   // made visible by the first barrier
+    if (single_chunk) load_chunk(0, a.Npad);   // made visible by the first barrier
+    // per-bit constants live in LDS, not in 64 scalar registers
+    if (tid < MAXB) {
+        lds_sf[tid] = tid < B ? a.sf[tid] : 1.0f;
+        lds_bg[tid] = tid < B ? a.bg[tid] : 0.0f;
+    }
 
     // XCD-aware tile walk: blocks with the same (blockIdx % 8) share an XCD
     // and therefore an L2; give each such group one contiguous run of tiles
@@ -120,75 +186,138 @@ decode_kernel(const DecodeArgs a)
         const int ty = (t / a.tiles_x) % a.tiles_y;
         const int z = t / (a.tiles_x * a.tiles_y);
         const int x0 = tx * TW, y0 = ty * TH;
+        const bool interior = a.fast_ok && y0 - R >= 0 && y0 + TH + R <= H && x0 - RA >= 0 &&
+                              x0 + TW + RA <= W;
 
         float x[PPT][MAXB];
+        uint32_t win[NTASK][WDW];
 
+        // ---- global -> register windows for one group of bits ----
+        auto prefetch = [&](int g) {
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            if (b < B) {
-                const PIX *plane = img + (int64_t)b * a.bit_stride + (int64_t)z * a.z_stride;
-                // ---- stage tile + halo (BORDER_REFLECT_101) ----
-                for (int i = tid; i < RH * RW; i += NTHREADS) {
-                    const int ry = i / RW, rx = i - ry * RW;
-                    const int gy = reflect101(y0 - R + ry, H);
-                    const int gx = reflect101(x0 - R + rx, W);
-                    raw[i] = plane[(int64_t)gy * W + gx];
-                }
-                __syncthreads();
-                // ---- horizontal pass: exact u32 (or f32) ----
-                for (int i = tid; i < RH * TW; i += NTHREADS) {
-                    const int ry = i >> 6, rx = i & 63;
-                    const PIX *p = raw + ry * RW + rx + R;
-                    if constexpr (std::is_same<PIX, uint16_t>::value) {
-                        uint32_t acc = a.kfix[R] * (uint32_t)p[0];
+            for (int k = 0; k < NTASK; ++k) {
+                const int q = tid + k * NTHREADS;
+                const int bit = g * GROUP + q / (RH * 16);
+                const int rem = q % (RH * 16);
+                const int row = rem >> 4, cg = rem & 15;
+                if (q < TASKS && bit < B) {
+                    const PIX *plane = img + (int64_t)bit * a.bit_stride + (int64_t)z * a.z_stride;
+                    const int gy = y0 - R + row, gx = x0 + 4 * cg - RA;
+                    if (interior) {
+                        const uint32_t *src =
+                            reinterpret_cast<const uint32_t *>(plane + (int64_t)gy * W + gx);
 #pragma unroll
-                        for (int j = 1; j <= R; ++j)
-                            acc += a.kfix[R + j] * ((uint32_t)p[-j] + (uint32_t)p[j]);
-                        hs[i] = acc;
+                        for (int d = 0; d < WDW; ++d) win[k][d] = src[d];
                     } else {
-                        float acc = a.kflt[R] * p[0];
+                        const PIX *rowp = plane + (int64_t)reflect101(gy, H) * W;
+                        PIX tmp[NW];
 #pragma unroll
-                        for (int j = 1; j <= R; ++j)
-                            acc = acc + a.kflt[R + j] * (p[-j] + p[j]);
-                        hs[i] = acc;
-                    }
-                }
-                __syncthreads();
-                // ---- vertical pass for this thread's PPT pixels ----
-                HT col[PPT + 2 * R];
+                        for (int j = 0; j < NW; ++j) tmp[j] = rowp[reflect101(gx + j, W)];
+                        if constexpr (IS_U16) {
 #pragma unroll
-                for (int j = 0; j < PPT + 2 * R; ++j)
-                    col[j] = hs[(wave * PPT + j) * TW + lane];
+                            for (int d = 0; d < WDW; ++d)
+                                win[k][d] = (uint32_t)tmp[2 * d] | ((uint32_t)tmp[2 * d + 1] << 16);
+                        } else {
 #pragma unroll
-                for (int o = 0; o < PPT; ++o) {
-                    float v;
-                    if constexpr (std::is_same<PIX, uint16_t>::value) {
-                        // V = sum k_j * H_j needs 48 bits: split H into 16-bit
-                        // halves, two exact u32 sums, out = (V + 2^31) >> 32
-                        uint32_t hi = a.kfix[R] * (col[o + R] >> 16);
-                        uint32_t lo = a.kfix[R] * (col[o + R] & 0xffffu);
-#pragma unroll
-                        for (int j = 1; j <= R; ++j) {
-                            hi += a.kfix[R + j] * ((col[o + R - j] >> 16) + (col[o + R + j] >> 16));
-                            lo += a.kfix[R + j] * ((col[o + R - j] & 0xffffu) + (col[o + R + j] & 0xffffu));
+                            for (int d = 0; d < WDW; ++d) win[k][d] = __float_as_uint(tmp[d]);
                         }
-                        const uint32_t out = (hi + (lo >> 16) + 0x8000u) >> 16;
-                        v = (float)out;
-                    } else {
-                        float acc = a.kflt[R] * col[o + R];
-#pragma unroll
-                        for (int j = 1; j <= R; ++j)
-                            acc = acc + a.kflt[R + j] * (col[o + R - j] + col[o + R + j]);
-                        v = acc;
                     }
-                    x[o][b] = (v - a.bg[b]) / a.sf[b];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < WDW; ++d) win[k][d] = 0u;
                 }
+            }
+        };
+
+        // ---- horizontal pass from the register windows into LDS ----
+        auto hpass = [&]() {
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k) {
+                const int q = tid + k * NTHREADS;
+                if (q < TASKS) {
+                    u32x4 v;
+                    if constexpr (IS_U16) {
+                        uint32_t p[NW];
+#pragma unroll
+                        for (int d = 0; d < WDW; ++d) {
+                            p[2 * d] = win[k][d] & 0xffffu;
+                            p[2 * d + 1] = win[k][d] >> 16;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = RA + j;
+                            uint32_t acc = a.kfix[R] * p[c];
+#pragma unroll
+                            for (int i = 1; i <= R; ++i) acc += a.kfix[R + i] * (p[c - i] + p[c + i]);
+                            v[j] = acc;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = RA + j;
+                            float acc = a.kflt[R] * __uint_as_float(win[k][c]);
+#pragma unroll
+                            for (int i = 1; i <= R; ++i)
+                                acc = acc + a.kflt[R + i] * (__uint_as_float(win[k][c - i]) +
+                                                             __uint_as_float(win[k][c + i]));
+                            v[j] = __float_as_uint(acc);
+                        }
+                    }
+                    // q = (bit_in_group * RH + row) * 16 + cg  ->  hs[4q .. 4q+3]
+                    reinterpret_cast<u32x4 *>(hs)[q] = v;
+                }
+            }
+        };
+
+        prefetch(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g * GROUP < B) {
+                hpass();
+                __syncthreads();
+                if (g + 1 < NG && (g + 1) * GROUP < B) prefetch(g + 1);
+                // ---- vertical pass for this thread's PPT pixels ----
+#pragma unroll
+                for (int i = 0; i < GROUP; ++i) {
+                    const int b = g * GROUP + i;
+                    const float sfb = lds_sf[b], bgb = lds_bg[b];
+                    HT col[PPT + 2 * R];
+#pragma unroll
+                    for (int j = 0; j < PPT + 2 * R; ++j)
+                        col[j] = hs[(i * RH + wave * PPT + j) * TW + lane];
+#pragma unroll
+                    for (int o = 0; o < PPT; ++o) {
+                        float v;
+                        if constexpr (IS_U16) {
+                            // V = sum k_j * H_j needs 48 bits: split H into 16-bit
+                            // halves, two exact u32 sums, out = (V + 2^31) >> 32
+                            uint32_t hi = a.kfix[R] * (col[o + R] >> 16);
+                            uint32_t lo = a.kfix[R] * (col[o + R] & 0xffffu);
+#pragma unroll
+                            for (int j = 1; j <= R; ++j) {
+                                hi += a.kfix[R + j] * ((col[o + R - j] >> 16) + (col[o + R + j] >> 16));
+                                lo += a.kfix[R + j] *
+                                      ((col[o + R - j] & 0xffffu) + (col[o + R + j] & 0xffffu));
+                            }
+                            v = (float)((hi + (lo >> 16) + 0x8000u) >> 16);
+                        } else {
+                            float acc = a.kflt[R] * col[o + R];
+#pragma unroll
+                            for (int j = 1; j <= R; ++j)
+                                acc = acc + a.kflt[R + j] * (col[o + R - j] + col[o + R + j]);
+                            v = acc;
+                        }
+                        x[o][b] = b < B ? (v - bgb) / sfb : 0.0f;
+                    }
+                }
+                __syncthreads();   // hs is rewritten by the next group
             } else {
 #pragma unroll
-                for (int o = 0; o < PPT; ++o) x[o][b] = 0.0f;
+                for (int i = 0; i < GROUP; ++i)
+#pragma unroll
+                    for (int o = 0; o < PPT; ++o) x[o][g * GROUP + i] = 0.0f;
             }
         }
-        (void)K;
 
         // ---- magnitude and L2 normalisation (decoding.py:106-110) ----
         float mag[PPT];
@@ -204,77 +333,127 @@ decode_kernel(const DecodeArgs a)
             for (int b = 0; b < MAXB; ++b) x[o][b] = x[o][b] / m;
         }
 
-        // ---- nearest codeword: float32 scores, running top-2 per pixel ----
-        float best[PPT], second[PPT];
-        int bi[PPT];
-#pragma unroll
-        for (int o = 0; o < PPT; ++o) { best[o] = -INFINITY; second[o] = -INFINITY; bi[o] = 0; }
-
-        for (int c0 = 0; c0 < N; c0 += a.chunk) {
-            const int cn = min(a.chunk, N - c0);
-            if (!single_chunk) {
-                __syncthreads();            // previous chunk fully consumed
-                load_chunk(c0, cn);
-                __syncthreads();
-            }
-            for (int n = 0; n < cn; ++n) {
-                const float *c = cb + n * MAXB;
-                float s[PPT];
-                const float h = hn[n];
-#pragma unroll
-                for (int o = 0; o < PPT; ++o) s[o] = -h;
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b) {
-                    const float cv = c[b];
-#pragma unroll
-                    for (int o = 0; o < PPT; ++o) s[o] = fmaf(x[o][b], cv, s[o]);
-                }
-#pragma unroll
-                for (int o = 0; o < PPT; ++o) {
-                    second[o] = __builtin_amdgcn_fmed3f(best[o], second[o], s[o]);
-                    bi[o] = s[o] > best[o] ? c0 + n : bi[o];
-                    best[o] = fmaxf(best[o], s[o]);
-                }
-            }
-        }
-
-        // ---- exact float64 distance of the winner; near-ties re-scored ----
+        // ---- nearest codeword on the matrix cores, one pixel row at a time ----
+        // bf16 operands: pk[s][ks][0..3] = bits 16ks+0..7, [4..7] = bits
+        // 16ks+8..15 of split s.  After the half swap, regs [0..3] are the B
+        // operand of pixel tile 0 (lanes 0-31's columns) and [4..7] of tile 1.
 #pragma unroll
         for (int o = 0; o < PPT; ++o) {
-            int win = bi[o];
-            double d2 = 0.0;
-            if (best[o] - second[o] < TIE_EPS) {
-                // every codeword whose float32 score is within TIE_EPS of the
-                // best is a candidate; float64 decides, lowest index on ties
-                d2 = INFINITY;
-                for (int n = 0; n < N; ++n) {
-                    const double *row = a.cb64 + (size_t)n * B;
-                    const float *crow = cb + n * MAXB;      // valid iff single_chunk
-                    float s = single_chunk ? -hn[n] : -half_norm(row, B);
+            Top2 st[2];
 #pragma unroll
-                    for (int b = 0; b < MAXB; ++b) {
-                        const float cv = single_chunk ? crow[b] : (b < B ? (float)row[b] : 0.0f);
-                        s = fmaf(x[o][b], cv, s);
-                    }
-                    if (s >= best[o] - TIE_EPS) {
-                        double e = 0.0;
+            for (int tt = 0; tt < 2; ++tt) {
+                st[tt].best = -INFINITY; st[tt].second = -INFINITY; st[tt].bi = 0;
+            }
+            uint32_t pk[3][KS][8];
 #pragma unroll
-                        for (int b = 0; b < MAXB; ++b)
-                            if (b < B) {
-                                const double tdiff = (double)x[o][b] - row[b];
-                                e = e + tdiff * tdiff;
-                            }
-                        if (e < d2) { d2 = e; win = n; }
+            for (int ks = 0; ks < KS; ++ks) {
+                float r[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r[j] = x[o][16 * ks + j];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                    for (int d = 0; d < 8; ++d)
+                        pk[s][ks][d] = __builtin_amdgcn_perm(__float_as_uint(r[2 * d + 1]),
+                                                             __float_as_uint(r[2 * d]), 0x07060302u);
+                    if (s < 2) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            r[j] = r[j] - __uint_as_float(__float_as_uint(r[j]) & 0xffff0000u);
                     }
                 }
-            } else {
-                const double *row = a.cb64 + (size_t)win * B;
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b)
-                    if (b < B) {
-                        const double tdiff = (double)x[o][b] - row[b];
-                        d2 = d2 + tdiff * tdiff;
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(pk[s][ks][d], pk[s][ks][4 + d],
+                                                                   false, false);
+                        pk[s][ks][d] = sw[0];
+                        pk[s][ks][4 + d] = sw[1];
                     }
+            }
+
+            for (int c0 = 0; c0 < a.Npad; c0 += a.chunk) {
+                const int cn = min(a.chunk, a.Npad - c0);
+                if (!single_chunk) {
+                    __syncthreads();            // previous chunk fully consumed
+                    load_chunk(c0, cn);
+                    __syncthreads();
+                }
+                for (int ct = 0; ct < cn; ct += 32) {
+                    // A operand: 8 bf16 of codeword (ct + lane&31), bits 16ks + 8*half ..
+                    u32x4 af[KS];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        af[ks] = *reinterpret_cast<const u32x4 *>(
+                            lds_a + ((size_t)(ct + (lane & 31)) * MAXB + 16 * ks + 8 * half) * 2);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) {
+                                u32x4 bv;
+                                bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
+                                bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, bv),
+                                    acc, 0, 0, 0);
+                            }
+                        // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of
+                        // pixel (lane&31) + 32*tt
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int nl = ct + 8 * gq + 4 * half;
+                            float s4[4];
+                            if (uniform) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    s4[i] = c0 + nl + i < a.N ? acc[4 * gq + i] : -INFINITY;
+                            } else {
+                                const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
+                                const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
+                                s4[0] = fmaf(vv.x, acc[4 * gq + 0], -hh.x);
+                                s4[1] = fmaf(vv.y, acc[4 * gq + 1], -hh.y);
+                                s4[2] = fmaf(vv.z, acc[4 * gq + 2], -hh.z);
+                                s4[3] = fmaf(vv.w, acc[4 * gq + 3], -hh.w);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) top2_update(st[tt], s4[i], c0 + nl + i);
+                        }
+                    }
+                }
+            }
+
+            // ---- merge lane halves, exact float64 distance, thresholds ----
+            // after the swaps both states in a lane belong to its own pixel
+            auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].best),
+                                                       __float_as_uint(st[1].best), false, false);
+            auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].second),
+                                                       __float_as_uint(st[1].second), false, false);
+            auto si = __builtin_amdgcn_permlane32_swap((unsigned)st[0].bi, (unsigned)st[1].bi,
+                                                       false, false);
+            const float b0 = __uint_as_float(sb[0]), b1 = __uint_as_float(sb[1]);
+            const float s0 = __uint_as_float(ss[0]), s1 = __uint_as_float(ss[1]);
+            const int i0 = (int)si[0], i1 = (int)si[1];
+            const float best = fmaxf(b0, b1);
+            const float second = fmaxf(fminf(b0, b1), fmaxf(s0, s1));
+            int win = b0 > b1 ? i0 : (b1 > b0 ? i1 : min(i0, i1));
+            // uniform codebooks compare raw on-bit sums (score / v): widen eps
+            const float eps = uniform ? TIE_EPS * 4.0f : TIE_EPS;
+
+            double d2 = exact_d2<MAXB>(x[o], g_mask[win], g_v64[win], B);
+            if (best - second < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN) {
+                // ambiguous and possibly within the threshold: exact scan,
+                // lowest index wins exact ties (the oracle's rule)
+                d2 = INFINITY;
+                for (int n = 0; n < a.N; ++n) {
+                    const double e = exact_d2<MAXB>(x[o], g_mask[n], g_v64[n], B);
+                    if (e < d2) { d2 = e; win = n; }
+                }
             }
             const double d = sqrt(d2);
 
@@ -294,36 +473,29 @@ decode_kernel(const DecodeArgs a)
                         if (b < B) tp[(int64_t)b * a.tr_b] = x[o][b];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the pixel rows from interleaving
         }
-        __syncthreads();   // tile buffers are reused by the next tile
     }
-}
-
-template <typename PIX, int R, int MAXB, int PPT>
-size_t tile_lds_bytes()
-{
-    using HT = typename HType<PIX>::type;
-    constexpr int TH = 4 * PPT, RH = TH + 2 * R, RW = TW + 2 * R;
-    return (((size_t)RH * RW * sizeof(PIX) + 15) & ~size_t(15)) + (size_t)RH * TW * sizeof(HT);
 }
 
 template <typename PIX, int R, int MAXB, int PPT>
 int launch(DecodeArgs &a, hipStream_t stream)
 {
-    constexpr int TH = 4 * PPT;
+    using HT = typename HType<PIX>::type;
+    constexpr int TH = 4 * PPT, RH = TH + 2 * R;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.Z;
     if (nt > INT32_MAX) return mf::fail(MF_EUNSUPPORTED, "too many tiles");
     a.n_tiles = (int)nt;
 
-    const size_t tile_bytes = tile_lds_bytes<PIX, R, MAXB, PPT>();
-    const size_t per_word = (size_t)MAXB * 4 + 4;
-    const size_t budget = 64 * 1024;
-    int chunk = (int)((budget - tile_bytes) / per_word);
-    if (chunk > a.N) chunk = a.N;
+    const size_t hs_bytes = (size_t)GROUP * RH * TW * sizeof(HT);
+    const size_t per_word = (size_t)MAXB * 2 + 8;
+    const size_t budget = 96 * 1024;
+    int chunk = (int)((budget - hs_bytes - 256) / per_word) & ~31;
+    if (chunk > a.Npad) chunk = a.Npad;
     a.chunk = chunk;
-    const size_t lds = tile_bytes + (size_t)chunk * per_word;
+    const size_t lds = hs_bytes + (size_t)chunk * per_word + 2 * MAXB * sizeof(float);
 
     const int cus = mf::device_cu_count();
     int64_t grid = (int64_t)cus * 4;
@@ -343,7 +515,6 @@ template <typename PIX, int R>
 int dispatch_bits(DecodeArgs &a, hipStream_t s)
 {
     if (a.B <= 16) return launch<PIX, R, 16, 4>(a, s);
-    if (a.B <= 24) return launch<PIX, R, 24, 2>(a, s);
     return launch<PIX, R, 32, 2>(a, s);
 }
 
@@ -353,7 +524,7 @@ int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
 #ifdef MF_DEV_BUILD   // development: only the sigma=1 kernels, quick compile
     if (R == 2) return dispatch_bits<PIX, 2>(a, s);
     return mf::fail(MF_EUNSUPPORTED, "dev build: R=2 only");
-#endif
+#else
     switch (R) {
     case 0: return dispatch_bits<PIX, 0>(a, s);
     case 1: return dispatch_bits<PIX, 1>(a, s);
@@ -362,9 +533,95 @@ int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
     case 4: return dispatch_bits<PIX, 4>(a, s);
     }
     return mf::fail(MF_EUNSUPPORTED, "blur radius %d > %d", R, MF_MAX_RADIUS);
+#endif
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+void table_layout(int N, int B, CbHeader &h)
+{
+    std::memset(&h, 0, sizeof(h));
+    h.magic = CB_MAGIC;
+    h.N = N;
+    h.B = B;
+    h.Npad = (N + 31) & ~31;
+    h.KB = B <= 16 ? 16 : 32;
+    size_t off = align256(sizeof(CbHeader));
+    h.off_a = (int64_t)off;    off += align256((size_t)h.Npad * h.KB * 2);
+    h.off_mask = (int64_t)off; off += align256((size_t)h.Npad * 4);
+    h.off_v = (int64_t)off;    off += align256((size_t)h.Npad * 4);
+    h.off_hn = (int64_t)off;   off += align256((size_t)h.Npad * 4);
+    h.off_v64 = (int64_t)off;  off += align256((size_t)h.Npad * 8);
+    h.off_cb64 = (int64_t)off; off += align256((size_t)N * B * 8);
+    h.total = (int64_t)off;
 }
 
 }  // namespace
+
+extern "C" int64_t mf_codebook_table_bytes(int N, int B)
+{
+    if (N < 1 || N > 32767 || B < 1 || B > MF_MAX_BITS)
+        return mf::fail(MF_EUNSUPPORTED, "codebook shape N=%d B=%d unsupported", N, B);
+    CbHeader h;
+    table_layout(N, B, h);
+    return h.total;
+}
+
+extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
+                                   int64_t table_bytes)
+{
+    if (!h_codebook || !table) return mf::fail(MF_EINVAL, "null pointer argument");
+    if (N < 1 || N > 32767 || B < 1 || B > MF_MAX_BITS)
+        return mf::fail(MF_EUNSUPPORTED, "codebook shape N=%d B=%d unsupported", N, B);
+    CbHeader h;
+    table_layout(N, B, h);
+    if (table_bytes < h.total)
+        return mf::fail(MF_EWORKSPACE, "codebook table %lld < %lld bytes", (long long)table_bytes,
+                        (long long)h.total);
+    std::vector<unsigned char> blob((size_t)h.total, 0);
+    uint16_t *am = reinterpret_cast<uint16_t *>(blob.data() + h.off_a);
+    uint32_t *mask = reinterpret_cast<uint32_t *>(blob.data() + h.off_mask);
+    float *vt = reinterpret_cast<float *>(blob.data() + h.off_v);
+    float *hn = reinterpret_cast<float *>(blob.data() + h.off_hn);
+    double *v64 = reinterpret_cast<double *>(blob.data() + h.off_v64);
+    double *cb = reinterpret_cast<double *>(blob.data() + h.off_cb64);
+    int uniform = 1;
+    double v_first = 0.0;
+    for (int n = 0; n < h.Npad; ++n) {
+        hn[n] = INFINITY;           // padding rows can never win
+        if (n >= N) continue;
+        double v = 0.0, sq = 0.0;
+        uint32_t m = 0;
+        for (int b = 0; b < B; ++b) {
+            const double c = h_codebook[(size_t)n * B + b];
+            cb[(size_t)n * B + b] = c;
+            if (c != 0.0) {
+                // MERFISH codewords are binary: every non-zero entry of a
+                // normalised row carries the same value
+                if (v != 0.0 && c != v)
+                    return mf::fail(MF_EUNSUPPORTED,
+                                    "codeword %d is not binary-valued (entries %g and %g)", n, v, c);
+                v = c;
+                m |= 1u << b;
+                am[(size_t)n * h.KB + b] = 0x3f80;    // bf16 1.0
+            }
+            sq += c * c;
+        }
+        mask[n] = m;
+        v64[n] = v;
+        vt[n] = (float)v;
+        hn[n] = (float)(0.5 * sq);
+        if (n == 0) v_first = v;
+        // uniform: every row has the same value and the same weight, so the
+        // raw on-bit sum orders the codewords
+        if (v != v_first || v <= 0.0 || __builtin_popcount(m) != __builtin_popcount(mask[0]))
+            uniform = 0;
+    }
+    h.uniform = uniform;
+    std::memcpy(blob.data(), &h, sizeof(h));
+    MF_HIP_CHECK(hipMemcpy(table, blob.data(), (size_t)h.total, hipMemcpyHostToDevice));
+    return MF_OK;
+}
 
 extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, float *h_float)
 {
@@ -409,14 +666,15 @@ extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, floa
 
 extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z, int H, int W,
                                 int64_t img_bit_stride, int64_t img_z_stride,
-                                const double *codebook, int N, const float *h_scale,
+                                const void *codebook_table, int N, const float *h_scale,
                                 const float *h_background, double sigma,
                                 double distance_threshold, float magnitude_threshold,
                                 int16_t *decoded, float *magnitudes, void *distances,
                                 int dist_dtype, float *traces, int64_t tr_z_stride,
                                 int64_t tr_bit_stride, void *stream)
 {
-    if (!image || !codebook || !h_scale || !h_background || !decoded || !magnitudes || !distances)
+    if (!image || !codebook_table || !h_scale || !h_background || !decoded || !magnitudes ||
+        !distances)
         return mf::fail(MF_EINVAL, "null pointer argument");
     if (B < 1 || B > MF_MAX_BITS)
         return mf::fail(MF_EUNSUPPORTED, "bit count %d outside 1..%d", B, MF_MAX_BITS);
@@ -428,8 +686,7 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
         return mf::fail(MF_EINVAL, "image dtype %d not u16/f32", image_dtype);
     if (dist_dtype != MF_DTYPE_F32 && dist_dtype != MF_DTYPE_F64)
         return mf::fail(MF_EINVAL, "distance dtype %d not f32/f64", dist_dtype);
-    if (!(sigma >= 0))
-        return mf::fail(MF_EINVAL, "sigma must be >= 0");
+    if (!(sigma >= 0)) return mf::fail(MF_EINVAL, "sigma must be >= 0");
     const int ksize = (int)(2 * std::ceil(2 * sigma) + 1);   // decoding.py:94
     const int R = ksize / 2;
     if (R > MF_MAX_RADIUS)
@@ -438,13 +695,21 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     if (R > H - 1 || R > W - 1)
         return mf::fail(MF_EINVAL, "image %dx%d smaller than blur radius %d", H, W, R);
 
+    CbHeader h;
+    table_layout(N, B, h);
     DecodeArgs a;
     std::memset(&a, 0, sizeof(a));
     a.img = image;
     a.bit_stride = img_bit_stride;
     a.z_stride = img_z_stride;
-    a.B = B; a.Z = Z; a.H = H; a.W = W; a.N = N;
-    a.cb64 = codebook;
+    a.B = B; a.Z = Z; a.H = H; a.W = W; a.N = N; a.Npad = h.Npad;
+    // the 4-byte window loads need even element offsets for u16 rows
+    a.fast_ok = image_dtype == MF_DTYPE_F32 ||
+                (!(W & 1) && !((img_bit_stride | img_z_stride) & 1) &&
+                 !(reinterpret_cast<uintptr_t>(image) & 3));
+    a.cbt = reinterpret_cast<const unsigned char *>(codebook_table);
+    a.off_a = h.off_a; a.off_mask = h.off_mask; a.off_v = h.off_v; a.off_hn = h.off_hn;
+    a.off_v64 = h.off_v64;
     for (int b = 0; b < B; ++b) { a.sf[b] = h_scale[b]; a.bg[b] = h_background[b]; }
     int rc = mf_gaussian_taps(ksize, sigma, a.kfix, a.kflt);
     if (rc) return rc;

@@ -121,9 +121,21 @@ class PixelBasedDecoder(object):
         return self._device
 
     def _codebook_device(self):
+        """Device codebook table (mf_codebook_prepare), built once."""
         if self._cb_dev is None:
-            self._cb_dev = torch.from_numpy(
-                np.ascontiguousarray(self._decodingMatrix)).to(self._dev())
+            import ctypes
+            L = _lib.lib()
+            N, B = self._decodingMatrix.shape
+            nbytes = _lib.check(L.mf_codebook_table_bytes(N, B))
+            dev = self._dev()
+            with torch.cuda.device(dev):
+                table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                cb = np.ascontiguousarray(self._decodingMatrix,
+                                          dtype=np.float64)
+                _lib.check(L.mf_codebook_prepare(
+                    cb.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), N, B,
+                    table.data_ptr(), nbytes))
+            self._cb_dev = table
         return self._cb_dev
 
     @staticmethod

@@ -172,17 +172,20 @@ def scaled_traces(filtered: np.ndarray, scale_factors, backgrounds):
 
 
 def nearest_codeword(norm_traces: np.ndarray, decoding_matrix: np.ndarray,
-                     chunk: int = 1 << 16):
+                     chunk: int = 1 << 16, return_gap: bool = False):
     """decoding.py:112-116 as exact float64 brute force.
-    norm_traces f32 [B, P] -> (distance f64 [P], index i64 [P])."""
+    norm_traces f32 [B, P] -> (distance f64 [P], index i64 [P]); with
+    return_gap also the squared-distance gap to the runner-up codeword."""
     B, P = norm_traces.shape
     N = decoding_matrix.shape[0]
     dist = np.empty(P, dtype=np.float64)
     idx = np.empty(P, dtype=np.int64)
+    gap = np.empty(P, dtype=np.float64)
     cm = np.asarray(decoding_matrix, dtype=np.float64)
     for s in range(0, P, chunk):
         x = norm_traces[:, s:s + chunk].astype(np.float64)     # [B, c]
         best = np.full(x.shape[1], np.inf)
+        second = np.full(x.shape[1], np.inf)
         bidx = np.zeros(x.shape[1], dtype=np.int64)
         for n in range(N):
             d2 = np.zeros(x.shape[1], dtype=np.float64)
@@ -190,20 +193,26 @@ def nearest_codeword(norm_traces: np.ndarray, decoding_matrix: np.ndarray,
                 t = x[b] - cm[n, b]
                 d2 = d2 + t * t
             m = d2 < best                                       # lowest n wins
+            second = np.where(m, best, np.minimum(second, d2))
             best[m] = d2[m]
             bidx[m] = n
         dist[s:s + chunk] = np.sqrt(best)
         idx[s:s + chunk] = bidx
+        gap[s:s + chunk] = second - best
+    if return_gap:
+        return dist, idx, gap
     return dist, idx
 
 
 def decode_pixels(image_data: np.ndarray, decoding_matrix: np.ndarray,
                   scale_factors=None, backgrounds=None,
                   distance_threshold: float = 0.5176,
-                  magnitude_threshold: float = 1, lowpass_sigma: float = 1):
+                  magnitude_threshold: float = 1, lowpass_sigma: float = 1,
+                  return_gap: bool = False):
     """decoding.py:46-131.  image_data [B, H, W] uint16 (or float32).
     Returns (decoded int16 [H,W], magnitudes f32 [H,W], traces f32 [B,H,W],
-    distances f64 [H,W])."""
+    distances f64 [H,W]) and, with return_gap, the squared-distance gap
+    between the nearest and second-nearest codeword per pixel."""
     B = image_data.shape[0]
     if scale_factors is None:
         scale_factors = np.ones(B)
@@ -220,11 +229,14 @@ def decode_pixels(image_data: np.ndarray, decoding_matrix: np.ndarray,
     shape = filtered.shape[1:]
     mag, norm = scaled_traces(filtered.reshape(B, -1), scale_factors,
                               backgrounds)
-    dist, idx = nearest_codeword(norm, decoding_matrix)
+    dist, idx, gap = nearest_codeword(norm, decoding_matrix, return_gap=True)
     decoded = np.where(dist <= distance_threshold, idx, -1).astype(np.int16)
     decoded[mag < magnitude_threshold] = -1
-    return (decoded.reshape(shape), mag.reshape(shape),
-            norm.reshape((B,) + shape), dist.reshape(shape))
+    out = (decoded.reshape(shape), mag.reshape(shape),
+           norm.reshape((B,) + shape), dist.reshape(shape))
+    if return_gap:
+        out = out + (gap.reshape(shape),)
+    return out
 
 
 # --------------------------------------------------------------------------

@@ -41,18 +41,31 @@ def _decode_gpu(dec, g):
 
 
 def _decode_oracle(g):
+    """oracle decode incl. the squared-distance gap to the runner-up."""
     p = g['p']
     dm = oracle.normalized_codebook(g['codebook'])
     img = g['image']
     if not p['decode3d']:
         return oracle.decode_pixels(img, dm, g['sf'], g['bg'], p['dthr'],
-                                    p['mthr'], p['sigma'])
+                                    p['mthr'], p['sigma'], return_gap=True)
     outs = [oracle.decode_pixels(img[:, z], dm, g['sf'], g['bg'], p['dthr'],
-                                 p['mthr'], p['sigma'])
+                                 p['mthr'], p['sigma'], return_gap=True)
             for z in range(img.shape[1])]
     return (np.array([o[0] for o in outs]), np.array([o[1] for o in outs]),
             np.array([o[2] for o in outs]),
-            np.array([o[3] for o in outs]).astype(np.float32))
+            np.array([o[3] for o in outs]).astype(np.float32),
+            np.array([o[4] for o in outs]))
+
+
+def assert_distances(d, od, gap, decoded):
+    """Distances are bit-exact wherever the winner is unambiguous (runner-up
+    more than 1e-4 away in squared distance, i.e. 5e-5 in score) or the pixel
+    decodes; an ambiguous far pixel may report either near-tied codeword, so
+    its distance agrees to float32-score rounding (documented in
+    include/merfish_hip.h)."""
+    clear = (gap > 1e-4) | (decoded >= 0)
+    assert np.array_equal(d[clear], od[clear])
+    np.testing.assert_allclose(d[~clear], od[~clear], rtol=2e-6, atol=0)
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -68,11 +81,11 @@ def test_decode_pixels_golden(name, gpu_device):
     np.testing.assert_allclose(npt, g['traces'], rtol=0, atol=5e-7)
     np.testing.assert_allclose(d, g['distances'], rtol=1e-6, atol=2e-7)
     # vs the oracle: same operation order, so bit-exact
-    odi, opm, onpt, od = _decode_oracle(g)
+    odi, opm, onpt, od, gap = _decode_oracle(g)
     assert np.array_equal(di, odi)
     assert np.array_equal(pm, opm)
     assert np.array_equal(npt, onpt)
-    assert np.array_equal(d, od)
+    assert_distances(d, od, gap, odi)
 
 
 @pytest.mark.parametrize('name', golden_names())
