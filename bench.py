@@ -122,7 +122,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ts = time.perf_counter()
         bc, vol = step(i)
+        if os.environ.get('BENCH_DEBUG'):
+            torch.cuda.synchronize(dev)
+            print('step', i, (time.perf_counter() - ts) * 1e3, file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:

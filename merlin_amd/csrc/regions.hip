@@ -92,24 +92,28 @@ ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int Z, int H, int W, int 
 __global__ void __launch_bounds__(NT)
 ccl_flatten(int32_t *L, int n, unsigned long long *counts)
 {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    int fg = 0, root = 0;
-    if (i < n) {
+    // grid-stride: each thread keeps private counts, one atomic pair per wave
+    // at the very end (a same-address atomic per 64 pixels serialises)
+    int fg = 0, roots = 0;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
         const int p = L[i];
         if (p >= 0) {
             int r = p;
             int q = L[r];
             while (q != r) { r = q; q = L[r]; }
             L[i] = r;
-            fg = 1;
-            root = r == i;
+            ++fg;
+            roots += r == i;
         }
     }
-    // one atomic per wave
-    const unsigned long long mf_ = __ballot(fg), mr_ = __ballot(root);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        fg += __shfl_down(fg, off);
+        roots += __shfl_down(roots, off);
+    }
     if ((threadIdx.x & 63) == 0) {
-        if (mf_) atomicAdd(counts + 0, (unsigned long long)__popcll(mf_));
-        if (mr_) atomicAdd(counts + 1, (unsigned long long)__popcll(mr_));
+        if (fg) atomicAdd(counts + 0, (unsigned long long)fg);
+        if (roots) atomicAdd(counts + 1, (unsigned long long)roots);
     }
 }
 
@@ -154,10 +158,16 @@ struct StatsArgs {
     float *inten, *mean_tm, *min_tm;
 };
 
+// 16 lanes per region: every lane walks the region's pixels (raster order) and
+// owns the bits sub, sub+16; the scalar statistics are computed redundantly
+// by the 16 lanes (same addresses, broadcast loads) and written by lane 0.
+constexpr int RSUB = 16;
+
 __global__ void __launch_bounds__(NT)
 region_stats(const StatsArgs a)
 {
-    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t r = ((int64_t)blockIdx.x * NT + threadIdx.x) / RSUB;
+    const int sub = threadIdx.x & (RSUB - 1);
     if (r >= a.n_reg) return;
     const int64_t i0 = a.offsets[r];
     const int64_t i1 = r + 1 < a.n_reg ? a.offsets[r + 1] : a.n_pix;
@@ -197,23 +207,25 @@ region_stats(const StatsArgs a)
     if (a.conn3d && !a.dist_f64) mean_d = (double)(float)mean_d;
     if (!a.conn3d) cz = first / plane;
 
-    double *row = a.rec + r * MF_REC_COLS;
-    row[0] = (double)a.dec[first];
-    row[1] = (double)(first / plane);
-    row[2] = (double)n;
-    row[3] = mean_int;
-    row[4] = (double)mmax;
-    row[5] = mean_d;
-    row[6] = dmin;
-    row[7] = cz;
-    row[8] = cy;
-    row[9] = cx;
-    row[10] = (double)first;
-    row[11] = 0.0;
+    if (sub == 0) {
+        double *row = a.rec + r * MF_REC_COLS;
+        row[0] = (double)a.dec[first];
+        row[1] = (double)(first / plane);
+        row[2] = (double)n;
+        row[3] = mean_int;
+        row[4] = (double)mmax;
+        row[5] = mean_d;
+        row[6] = dmin;
+        row[7] = cz;
+        row[8] = cy;
+        row[9] = cx;
+        row[10] = (double)first;
+        row[11] = 0.0;
+    }
 
     // per-bit means: sequential float32 sums in raster order, then / n
     // (np.mean(list of f32 rows, axis 0), decoding.py:197, 220, 330)
-    for (int b = 0; b < a.B; ++b) {
+    for (int b = sub; b < a.B; b += RSUB) {
         float s = 0.0f, stm = 0.0f, mn = INFINITY;
         for (int64_t i = i0; i < i1; ++i) {
             const int p = a.pix[i];
@@ -296,7 +308,8 @@ extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, 
     MF_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), s));
     hipLaunchKernelGGL(ccl_init, dim3(grid), dim3(NT), 0, s, decoded, labels, n);
     hipLaunchKernelGGL(ccl_merge, dim3(grid), dim3(NT), 0, s, decoded, labels, Z, H, W, conn3d);
-    hipLaunchKernelGGL(ccl_flatten, dim3(grid), dim3(NT), 0, s, labels, n,
+    const unsigned fgrid = grid < 2048u ? grid : 2048u;
+    hipLaunchKernelGGL(ccl_flatten, dim3(fgrid), dim3(NT), 0, s, labels, n,
                        reinterpret_cast<unsigned long long *>(counts));
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
@@ -367,7 +380,7 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride;
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.conn3d = conn3d;
     a.rec = rec; a.inten = inten; a.mean_tm = mean_tm; a.min_tm = min_tm;
-    const unsigned gr = (unsigned)((n_regions + NT - 1) / NT);
+    const unsigned gr = (unsigned)((n_regions * RSUB + NT - 1) / NT);
     hipLaunchKernelGGL(region_stats, dim3(gr), dim3(NT), 0, s, a);
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;

@@ -7,10 +7,7 @@ the same products: the barcode table the task writes to the barcode database
 (decode.py:225-230) and the decoded / magnitude / distance images
 (decode.py:113-127).  Parameter names and defaults are the task's
 (decode.py:46-66)."""
-from typing import Optional
-
 import numpy as np
-import pandas
 import torch
 
 from merlin_amd.decoding import PixelBasedDecoder, DecodedVolume
@@ -54,27 +51,20 @@ class Decode(object):
                 fov: int, globalAligner=None, zPositions=None):
         """decode.py:92-175 for one FOV.  Returns (barcodes DataFrame,
         DecodedVolume); the volume's decoded/magnitudes/distances tensors are
-        the images _save_decoded_images would write."""
+        the images _save_decoded_images would write.
+
+        2-D mode labels every plane in one pass and emits the rows in the
+        order the reference writes them (plane, barcode index, label order);
+        decode_3d labels the volume with 26-connectivity."""
         p = self.parameters
         vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
-        Z = vol.shape[0]
-        if p['decode_3d']:
-            bc = self.decoder.extract_barcodes(
-                vol, fov, self.cropWidth, None, globalAligner,
-                p['minimum_area'], is3D=True)
-        else:
-            frames = []
-            table = self.decoder.region_table(vol, False)
-            for z in range(Z):
-                rows = np.nonzero(table.rec[:, 1] == z)[0]
-                frames.append(self.decoder._frame_from_rows(
-                    table, rows, False, vol.bit_count, fov, self.cropWidth,
-                    z, globalAligner, p['minimum_area'], vol.shape[1:]))
-            bc = pandas.concat(frames) if frames else pandas.DataFrame()
+        bc = self.decoder.extract_barcodes(
+            vol, fov, self.cropWidth, None, globalAligner, p['minimum_area'],
+            is3D=bool(p['decode_3d']))
         if p['remove_z_duplicated_barcodes']:
             from merlin_amd import barcodefilters
             zpos = zPositions if zPositions is not None \
-                else list(range(Z))
+                else list(range(vol.shape[0]))
             bc = barcodefilters.remove_zplane_duplicates_all_barcodeids(
                 bc, p['z_duplicate_zPlane_threshold'],
                 p['z_duplicate_xy_pixel_threshold'], zpos)

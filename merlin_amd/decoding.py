@@ -63,16 +63,29 @@ class DecodedVolume(object):
 
 
 class RegionTable(object):
-    """Host copy of mf_region_table's output, rows in reference order."""
+    """mf_region_table's output, rows in reference order.  The tensors stay on
+    the GPU; the host copies are made on first use."""
 
     def __init__(self, rec, inten, mean_tm=None, min_tm=None):
-        self.rec = rec
-        self.inten = inten
-        self.mean_tm = mean_tm
-        self.min_tm = min_tm
+        self.rec_d = rec
+        self.inten_d = inten
+        self.mean_tm_d = mean_tm
+        self.min_tm_d = min_tm
+        self._host = {}
+
+    def _h(self, name):
+        if name not in self._host:
+            t = getattr(self, name + '_d')
+            self._host[name] = None if t is None else t.cpu().numpy()
+        return self._host[name]
+
+    rec = property(lambda self: self._h('rec'))
+    inten = property(lambda self: self._h('inten'))
+    mean_tm = property(lambda self: self._h('mean_tm'))
+    min_tm = property(lambda self: self._h('min_tm'))
 
     def __len__(self):
-        return self.rec.shape[0]
+        return self.rec_d.shape[0]
 
 
 class PixelBasedDecoder(object):
@@ -103,6 +116,7 @@ class PixelBasedDecoder(object):
         self._device = torch.device(device) if device is not None else None
         self._cb_dev = None
         self._recent = []       # [(weakrefs of returned arrays, DecodedVolume)]
+        self._pin = {}
 
     # ------------------------------------------------------------ helpers --
 
@@ -341,10 +355,7 @@ class PixelBasedDecoder(object):
                     tr.stride(1), labels.data_ptr(), B, Z, H, W, int(is3D),
                     n_pix, n_reg, rec.data_ptr(), inten.data_ptr(),
                     _ptr(mean_tm), _ptr(min_tm), ws.data_ptr(), ws_bytes, sp))
-            table = RegionTable(
-                rec.cpu().numpy(), inten.cpu().numpy(),
-                None if mean_tm is None else mean_tm.cpu().numpy(),
-                None if min_tm is None else min_tm.cpu().numpy())
+            table = RegionTable(rec, inten, mean_tm, min_tm)
         vol._tables[key] = table
         vol.labels = labels
         return table
@@ -353,50 +364,135 @@ class PixelBasedDecoder(object):
 
     def _frame_from_rows(self, table: RegionTable, rows, is3D, bitCount,
                          fov, cropWidth, zIndex, globalAligner, minimumArea,
-                         cropShape) -> pandas.DataFrame:
+                         cropShape, zFromTable=False) -> pandas.DataFrame:
         """Assemble the reference's DataFrame (decoding.py:171-252) for the
-        given region rows."""
+        given region rows (one barcode index, or every index in reference
+        order).  With zFromTable the z column is each row's own plane (a
+        multi-plane 2-D volume), else zIndex."""
         intensityColumns = ['intensity_{}'.format(i) for i in range(bitCount)]
         rec = table.rec[rows]
         n = rec.shape[0]
         if n == 0:
             return pandas.DataFrame(columns=COLUMN_NAMES + intensityColumns)
 
-        centroids = np.zeros((n, 3))
+        centroids = np.empty((n, 3))
         # reference order: [z, x (column), y (row)] (decoding.py:188, 209-211)
         if is3D:
             centroids[:, 0] = rec[:, 7]
+        elif zFromTable:
+            centroids[:, 0] = rec[:, 1]
         else:
             centroids[:, 0] = zIndex if zIndex is not None else np.nan
         centroids[:, 1] = rec[:, 9]
         centroids[:, 2] = rec[:, 8]
         if globalAligner is not None:
-            globalCentroids = globalAligner.fov_coordinate_array_to_global(
-                fov, centroids)
+            globalCentroids = np.asarray(
+                globalAligner.fov_coordinate_array_to_global(fov, centroids))
         else:
             globalCentroids = centroids
 
-        df = pandas.DataFrame(np.zeros((n, len(COLUMN_NAMES))),
-                              columns=COLUMN_NAMES)
-        df['barcode_id'] = rec[:, 0].astype(np.int64)
-        df['fov'] = fov
-        df[['mean_intensity', 'max_intensity', 'area']] = rec[:, [3, 4, 2]]
-        df[['mean_distance', 'min_distance']] = rec[:, [5, 6]]
-        df[['x', 'y', 'z']] = centroids[:, [1, 2, 0]]
-        df[['global_x', 'global_y', 'global_z']] = \
-            np.asarray(globalCentroids)[:, [1, 2, 0]]
-        df['cell_index'] = -1
-        intensities = pandas.DataFrame(table.inten[rows],
-                                       columns=intensityColumns)
-        fullDF = pandas.concat([df, intensities], axis=1)
         # exclusive crop on the centroid, quirks included: x is compared with
         # shape[0] and y with shape[1] of the decoded image (decoding.py:244)
-        keep = ((fullDF['x'] > cropWidth)
-                & (fullDF['x'] < cropShape[0] - cropWidth)
-                & (fullDF['y'] > cropWidth)
-                & (fullDF['y'] < cropShape[1] - cropWidth)
-                & (fullDF['area'] >= minimumArea))
-        return fullDF[keep]
+        x, y, area = centroids[:, 1], centroids[:, 2], rec[:, 2]
+        keep = ((x > cropWidth) & (x < cropShape[0] - cropWidth)
+                & (y > cropWidth) & (y < cropShape[1] - cropWidth)
+                & (area >= minimumArea))
+        # index = position inside the per-(plane, barcode) frame the reference
+        # builds before concatenating (decode.py:225-230)
+        gkey = rec[:, 1] * 65536.0 + rec[:, 0] if not is3D else rec[:, 0]
+        starts = np.flatnonzero(np.r_[True, gkey[1:] != gkey[:-1]])
+        pos = np.arange(n) - np.repeat(starts, np.diff(np.r_[starts, n]))
+        sel = np.flatnonzero(keep)
+        cols = {
+            'barcode_id': rec[sel, 0].astype(np.int64),
+            'fov': np.full(len(sel), fov),
+            'mean_intensity': rec[sel, 3],
+            'max_intensity': rec[sel, 4],
+            'area': rec[sel, 2],
+            'mean_distance': rec[sel, 5],
+            'min_distance': rec[sel, 6],
+            'x': centroids[sel, 1],
+            'y': centroids[sel, 2],
+            'z': centroids[sel, 0],
+            'global_x': globalCentroids[sel, 1],
+            'global_y': globalCentroids[sel, 2],
+            'global_z': globalCentroids[sel, 0],
+            'cell_index': np.full(len(sel), -1, dtype=np.int64),
+        }
+        inten = table.inten[rows][sel]
+        for i, c in enumerate(intensityColumns):
+            cols[c] = inten[:, i]
+        return pandas.DataFrame(cols, index=pos[sel], copy=False)
+
+    def _pinned(self, name, shape, dtype):
+        """Reusable page-locked staging buffer (D2H at full PCIe rate)."""
+        n = int(np.prod(shape))
+        buf = self._pin.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+            self._pin[name] = buf
+        return buf[:n].view(shape)
+
+    def _frame_on_device(self, table: RegionTable, is3D, bitCount, fov,
+                         cropWidth, globalAligner, minimumArea, cropShape
+                         ) -> pandas.DataFrame:
+        """_frame_from_rows for every row of a device-resident table: the crop
+        / area filter and the column gather run on the GPU, so only the kept
+        rows cross PCIe, already column-major.  globalAligner is applied to
+        the kept rows (it is a per-row affine map, globalalign.py:141-148)."""
+        intensityColumns = ['intensity_{}'.format(i) for i in range(bitCount)]
+        rec = table.rec_d
+        n = rec.shape[0]
+        if n == 0:
+            return pandas.DataFrame(columns=COLUMN_NAMES + intensityColumns)
+        dev = rec.device
+        with torch.cuda.device(dev):
+            x, y, area = rec[:, 9], rec[:, 8], rec[:, 2]
+            keep = ((x > cropWidth) & (x < cropShape[0] - cropWidth)
+                    & (y > cropWidth) & (y < cropShape[1] - cropWidth)
+                    & (area >= minimumArea))
+            gkey = rec[:, 0] if is3D else rec[:, 1] * 65536.0 + rec[:, 0]
+            ar = torch.arange(n, device=dev)
+            first = torch.ones(n, dtype=torch.bool, device=dev)
+            first[1:] = gkey[1:] != gkey[:-1]
+            start = torch.cummax(torch.where(first, ar, torch.zeros_like(ar)),
+                                 0).values
+            sel = torch.nonzero(keep).squeeze(1)
+            zcol = 7 if is3D else 1
+            out64 = torch.stack([
+                rec[sel, 0], rec[sel, 3], rec[sel, 4], rec[sel, 2],
+                rec[sel, 5], rec[sel, 6], rec[sel, 9], rec[sel, 8],
+                rec[sel, zcol], (ar - start)[sel].to(torch.float64)])
+            out32 = table.inten_d[sel].t().contiguous()
+            m = out64.shape[1]
+            h64 = self._pinned('frame64', out64.shape, torch.float64)
+            h32 = self._pinned('frame32', out32.shape, torch.float32)
+            h64.copy_(out64, non_blocking=True)
+            h32.copy_(out32, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+        a64 = h64.numpy().copy()
+        a32 = h32.numpy().copy()
+        xs, ys, zs = a64[6], a64[7], a64[8]
+        if globalAligner is not None:
+            centroids = np.stack([zs, xs, ys], axis=1)
+            g = np.asarray(globalAligner.fov_coordinate_array_to_global(
+                fov, centroids))
+            gx, gy, gz = g[:, 1], g[:, 2], g[:, 0]
+        else:
+            gx, gy, gz = xs, ys, zs
+        cols = {
+            'barcode_id': a64[0].astype(np.int64),
+            'fov': np.full(m, fov),
+            'mean_intensity': a64[1], 'max_intensity': a64[2],
+            'area': a64[3], 'mean_distance': a64[4], 'min_distance': a64[5],
+            'x': xs, 'y': ys, 'z': zs,
+            'global_x': gx, 'global_y': gy, 'global_z': gz,
+            'cell_index': np.full(m, -1, dtype=np.int64),
+        }
+        for i, c in enumerate(intensityColumns):
+            cols[c] = a32[i]
+        return pandas.DataFrame(cols, index=a64[9].astype(np.int64),
+                                copy=False)
 
     def extract_barcodes_with_index(
             self, barcodeIndex: int, decodedImage: np.ndarray,
@@ -427,12 +523,15 @@ class PixelBasedDecoder(object):
         (analysis/decode.py:225-230), from a device-resident volume.
         In 2-D mode ``zPlane`` selects one plane of a multi-plane volume."""
         table = self.region_table(vol, is3D)
-        if is3D or zPlane is None:
-            rows = np.arange(len(table))
-        else:
-            rows = np.nonzero(table.rec[:, 1] == zPlane)[0]
         Z, H, W = vol.shape
         cropShape = (Z, H, W) if is3D else (H, W)
+        if is3D or (zPlane is None and zIndex is None):
+            # every row; in 2-D mode the z column is each row's own plane
+            return self._frame_on_device(
+                table, is3D, vol.bit_count, fov, cropWidth, globalAligner,
+                minimumArea, cropShape)
+        rows = np.arange(len(table)) if zPlane is None \
+            else np.nonzero(table.rec[:, 1] == zPlane)[0]
         return self._frame_from_rows(
             table, rows, is3D, vol.bit_count, fov, cropWidth, zIndex,
             globalAligner, minimumArea, cropShape)

@@ -79,3 +79,26 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+def synth_stack(codebook, shape, n_spots, seed, amp=(1000, 5000), bg=100,
+                psf=1.2):
+    """numpy Poisson background + Gaussian spots, uint16 [B, (Z,) H, W]."""
+    rng = np.random.default_rng(seed)
+    N, B = codebook.shape
+    img = rng.poisson(bg, size=(B,) + tuple(shape)).astype(np.float64)
+    H, W = shape[-2:]
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(n_spots):
+        b = rng.integers(N)
+        cy, cx = rng.uniform(2, H - 2), rng.uniform(2, W - 2)
+        a = rng.uniform(*amp)
+        spot = a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * psf ** 2))
+        on = np.nonzero(codebook[b])[0]
+        if len(shape) == 3:
+            zc = rng.integers(shape[0])
+            for zz in range(max(0, zc - 1), min(shape[0], zc + 2)):
+                img[on, zz] += (1.0 if zz == zc else 0.5) * spot
+        else:
+            img[on] += spot
+    return np.clip(np.rint(img), 0, 65535).astype(np.uint16)

@@ -1,0 +1,96 @@
+"""GPU: the FOV runner (device-resident, all planes in one launch, device-side
+record filter) against the per-index drop-in API and the oracle."""
+import warnings
+
+import numpy as np
+import pandas
+import pytest
+
+import merfish_oracle as oracle
+from conftest import (ArrayCodebook, AffineAligner, frame_to_array,
+                      load_golden, synth_stack)
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_fov(cb, img, sf, bg, params, fov, tform, decode3d):
+    dm = oracle.normalized_codebook(cb)
+    B, Z = img.shape[:2]
+    outs = [oracle.decode_pixels(img[:, z], dm, sf, bg,
+                                 params['distance_threshold'], 1,
+                                 params['lowpass_sigma']) for z in range(Z)]
+    frames = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if decode3d:
+            di = np.array([o[0] for o in outs])
+            pm = np.array([o[1] for o in outs])
+            npt = np.array([o[2] for o in outs])
+            d = np.array([o[3] for o in outs]).astype(np.float32)
+            frames.append(oracle.extract_all_barcodes(
+                cb.shape[0], di, pm, npt, d, fov, params['crop_width'], None,
+                tform, params['minimum_area']))
+        else:
+            for z, (di, pm, npt, d) in enumerate(outs):
+                frames.append(oracle.extract_all_barcodes(
+                    cb.shape[0], di, pm, npt, d, fov, params['crop_width'], z,
+                    tform, params['minimum_area']))
+        return pandas.concat(frames)
+
+
+@pytest.mark.parametrize('decode3d', [False, True])
+def test_run_fov_matches_oracle(gpu_device, decode3d):
+    import torch
+    from merlin_amd.decode import Decode
+    cb = load_golden('g2_synth192')['codebook']
+    shape = (24, 40, 72) if decode3d else (3, 80, 136)
+    img = synth_stack(cb, shape, 90, seed=21)
+    rng = np.random.default_rng(3)
+    sf = rng.uniform(300, 600, 16)
+    bg = rng.uniform(90, 110, 16)
+    tform = np.float32([[0.108, 0, 3.5], [0, 0.108, -2.25], [0, 0, 1]])
+    params = {'crop_width': 4, 'minimum_area': 2, 'distance_threshold': 0.5167,
+              'lowpass_sigma': 1, 'decode_3d': decode3d}
+    task = Decode(ArrayCodebook(cb), params, device=gpu_device)
+    bc, vol = task.run_fov(torch.from_numpy(img).to(gpu_device), sf, bg,
+                           fov=5, globalAligner=AffineAligner(tform))
+    exp = _oracle_fov(cb, img, sf, bg, task.parameters, 5, tform, decode3d)
+    r, e = frame_to_array(bc, 16), frame_to_array(exp, 16)
+    assert r.shape == e.shape and len(r) > 10
+    for c in (0, 1, 4, 13):
+        assert np.array_equal(r[:, c], e[:, c])
+    np.testing.assert_allclose(r, e, rtol=1e-6, atol=1e-6)
+    if not decode3d:
+        np.testing.assert_allclose(r[:, :14], e[:, :14], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(r[:, 14:], e[:, 14:])
+        assert np.array_equal(bc.index.to_numpy(), exp.index.to_numpy())
+    assert list(bc.columns) == list(exp.columns)
+    assert bc['barcode_id'].dtype == np.int64
+    assert bc['intensity_0'].dtype == np.float32
+
+
+def test_run_fov_matches_drop_in_api(gpu_device):
+    """run_fov == Decode's own loop over planes and barcode indexes through
+    decode_pixels / extract_barcodes_with_index (decode.py:118-127, 225-230)."""
+    import torch
+    from merlin_amd.decode import Decode
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    img = synth_stack(cb, (2, 96, 128), 80, seed=4)
+    sf = np.full(16, 400.0)
+    bg = np.zeros(16)
+    params = {'crop_width': 3}
+    task = Decode(ArrayCodebook(cb), params, device=gpu_device)
+    bc, vol = task.run_fov(torch.from_numpy(img).to(gpu_device), sf, bg, fov=1)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    frames = []
+    for z in range(2):
+        di, pm, npt, d = dec.decode_pixels(img[:, z], sf, bg,
+                                           distanceThreshold=0.5167)
+        assert np.array_equal(di, vol.decoded[z].cpu().numpy())
+        assert np.array_equal(d, vol.distances[z].cpu().numpy())
+        frames += [dec.extract_barcodes_with_index(i, di, pm, npt, d, 1, 3, z)
+                   for i in range(cb.shape[0])]
+    exp = pandas.concat([f for f in frames if len(f)])
+    assert np.array_equal(frame_to_array(bc, 16), frame_to_array(exp, 16))
+    assert np.array_equal(bc.index.to_numpy(), exp.index.to_numpy())
