@@ -1,0 +1,262 @@
+"""Scale-factor / background optimisation loop: the MI355X counterpart of
+merlin/analysis/optimize.py::OptimizeIteration (optimize.py:15-416, chromatic
+correction excluded: default off, optimize.py:31-32).
+
+In the reference every fragment (a random (fov, z) draw) runs in its own
+process and the cross-fragment reduction goes through ``.npy`` files on a
+shared file system (writers optimize.py:123-131, readers :328-340, :358-373,
+:406-408).  Here fragments are sharded over the ranks of a
+``torch.distributed`` group (one rank per GPU, RCCL over xGMI) and the one
+exchange step per iteration is a sum-all-reduce of zero-initialised ``[F, .]``
+matrices in which every rank fills only its own rows -- bit-exact because
+``x + 0 == x`` (NaN rows stay NaN) -- followed by the reference's nanmedian on
+every rank.  Parameter names and defaults are the task's (optimize.py:25-50).
+"""
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from merlin_amd.decoding import PixelBasedDecoder
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def shard_fragments(count: int, rank: int, world: int) -> List[int]:
+    """Fragment i belongs to rank i mod world (fragments are independent:
+    optimize.py:65-66, 78)."""
+    return list(range(rank, count, world))
+
+
+def all_gather_rows(local: np.ndarray, rows: Sequence[int], total: int,
+                    device=None, group=None) -> np.ndarray:
+    """Every rank contributes ``local[k]`` as row ``rows[k]`` of a [total, C]
+    float64 matrix; returns the full matrix on every rank.  Implemented as a
+    sum-all-reduce over a zero-initialised buffer (exact: x + 0 == x)."""
+    local = np.asarray(local, dtype=np.float64)
+    cols = local.shape[1:] if local.ndim > 1 else ()
+    full = np.zeros((total,) + tuple(cols), dtype=np.float64)
+    if len(rows):
+        full[list(rows)] = local
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        return full
+    backend = dist.get_backend(group)
+    t = torch.from_numpy(full)
+    if backend == 'nccl':
+        t = t.to(device if device is not None
+                 else torch.device('cuda', torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def pixel_histogram(stack: torch.Tensor) -> torch.Tensor:
+    """Per-bit histogram of a uint16 stack [B, ...] with the reference's bins
+    (np.arange(0, 65535): 65534 bins, the last one closed; preprocess.py:
+    110-131).  Returns float64 [B, 65534] on the stack's device."""
+    B = stack.shape[0]
+    out = torch.zeros((B, 65534), dtype=torch.float64, device=stack.device)
+    for b in range(B):
+        h = torch.bincount(stack[b].reshape(-1).to(torch.int32),
+                           minlength=65536)
+        out[b] = h[:65534].double()
+        out[b, 65533] += h[65534].double()     # np.histogram's closed last bin
+    return out
+
+
+def initial_scale_factors(pixelHistograms: np.ndarray) -> np.ndarray:
+    """optimize.py:140-155: argmin |cdf - 0.9| + 2 per bit."""
+    h = np.asarray(pixelHistograms, dtype=np.float64)
+    out = np.zeros(h.shape[0])
+    for i in range(h.shape[0]):
+        c = np.cumsum(h[i])
+        c = c / c[-1]
+        out[i] = np.argmin(np.abs(c - 0.9)) + 2
+    return out
+
+
+def summed_pixel_histogram(local: torch.Tensor, group=None) -> np.ndarray:
+    """preprocess.py:23-33 (sum of the per-FOV histograms) across ranks: a
+    genuine sum-all-reduce of a [B, 65534] float64 matrix."""
+    dist = _dist()
+    t = local.clone()
+    if dist is not None and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) != 'nccl':
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+class OptimizeIteration(object):
+    """One iteration of the scale-factor optimisation.
+
+    ``fragmentFunction(decoder, fovIndex, zIndex, scaleFactors, backgrounds)``
+    returns ``(refactors[B], backgroundRefactors[B], barcodesSeen[N])`` for one
+    fragment; the default decodes ``imageProvider(fov, z)`` (a uint16 [B,H,W]
+    tensor) on the GPU exactly as optimize.py:100-112 does."""
+
+    def __init__(self, codebook, parameters=None, fovs: Sequence[int] = (0,),
+                 zCount: int = 1, previousIteration=None,
+                 initialScaleFactors: Optional[np.ndarray] = None,
+                 imageProvider: Optional[Callable] = None,
+                 fragmentFunction: Optional[Callable] = None,
+                 device=None, group=None, seed: Optional[int] = None):
+        self.parameters = dict(parameters or {})
+        p = self.parameters
+        p.setdefault('fov_per_iteration', 50)
+        p.setdefault('area_threshold', 5)
+        p.setdefault('optimize_background', False)
+        p.setdefault('optimize_chromatic_correction', False)
+        p.setdefault('crop_width', 0)
+        if p['optimize_chromatic_correction']:
+            raise NotImplementedError('chromatic correction is out of scope')
+        if 'fov_index' in p:
+            p['fov_per_iteration'] = len(p['fov_index'])
+        else:
+            # optimize.py:43-50; every rank must draw the same fragments
+            rng = np.random.RandomState(seed)
+            p['fov_index'] = [
+                [int(rng.choice(list(fovs))), int(rng.choice(list(range(zCount))))]
+                for _ in range(p['fov_per_iteration'])]
+        self._codebook = codebook
+        self._previous = previousIteration
+        self._initial = None if initialScaleFactors is None \
+            else np.asarray(initialScaleFactors, dtype=np.float64)
+        self._provider = imageProvider
+        self._fragment_fn = fragmentFunction or self._decode_fragment
+        self._device = device
+        self._group = group
+        self._bits = int(np.asarray(codebook.get_barcodes()).shape[1])
+        self._codes = int(np.asarray(codebook.get_barcodes()).shape[0])
+        self._complete = False
+        self._decoder = None
+        self.barcodes = {}        # fragment -> DataFrame (this rank's only)
+
+    # ---------------------------------------------------------- helpers --
+
+    def fragment_count(self):
+        return self.parameters['fov_per_iteration']
+
+    def get_codebook(self):
+        return self._codebook
+
+    def _get_previous_scale_factors(self) -> np.ndarray:
+        """optimize.py:157-165"""
+        if self._previous is None:
+            if self._initial is None:
+                raise ValueError('the first iteration needs '
+                                 'initialScaleFactors (optimize.py:140-155)')
+            return self._initial.copy()
+        return self._previous.get_scale_factors()
+
+    def _get_previous_backgrounds(self) -> np.ndarray:
+        """optimize.py:167-175"""
+        if self._previous is None:
+            return np.zeros(self._bits)
+        return self._previous.get_backgrounds()
+
+    def _decode_fragment(self, decoder, fovIndex, zIndex, scaleFactors,
+                         backgrounds):
+        """optimize.py:100-122 for one fragment on the GPU."""
+        if self._provider is None:
+            raise ValueError('imageProvider is required')
+        img = self._provider(fovIndex, zIndex)
+        vol = decoder.decode_pixels_device(img, scaleFactors, backgrounds)
+        out = decoder.extract_refactors_device(
+            vol, self.parameters['optimize_background'])
+        self._last_volume = vol
+        return out
+
+    # -------------------------------------------------------------- run --
+
+    def run(self):
+        """Run this rank's fragments, then the exchange step."""
+        p = self.parameters
+        dist = _dist()
+        rank = dist.get_rank(self._group) if dist else 0
+        world = dist.get_world_size(self._group) if dist else 1
+        F = p['fov_per_iteration']
+        mine = shard_fragments(F, rank, world)
+
+        scaleFactors = self._get_previous_scale_factors()
+        backgrounds = self._get_previous_backgrounds()
+        if self._decoder is None and self._fragment_fn == self._decode_fragment:
+            self._decoder = PixelBasedDecoder(self._codebook,
+                                              device=self._device)
+        if self._decoder is not None:
+            self._decoder.refactorAreaThreshold = p['area_threshold']
+
+        rf = np.zeros((len(mine), self._bits))
+        bgr = np.zeros((len(mine), self._bits))
+        seen = np.zeros((len(mine), self._codes))
+        for k, frag in enumerate(mine):
+            fovIndex, zIndex = p['fov_index'][frag]
+            self._last_volume = None
+            rf[k], bgr[k], seen[k] = self._fragment_fn(
+                self._decoder, fovIndex, zIndex, scaleFactors, backgrounds)
+            if self._last_volume is not None and self._decoder is not None:
+                # optimize.py:116-122: the fragment's barcodes
+                self.barcodes[frag] = self._decoder.extract_barcodes(
+                    self._last_volume, fovIndex, p['crop_width'], zIndex,
+                    None, p['area_threshold'], zPlane=0)
+                self._last_volume = None
+
+        # one exchange per iteration (every rank used the same previous
+        # factors, so previous_scale_factors[F,B] is a broadcast row)
+        self._refactors = all_gather_rows(rf, mine, F, self._device, self._group)
+        self._bg_refactors = all_gather_rows(bgr, mine, F, self._device,
+                                             self._group)
+        self._counts = all_gather_rows(seen, mine, F, self._device, self._group)
+        self._previous_factors = np.tile(scaleFactors, (F, 1))
+        self._previous_backgrounds = np.tile(backgrounds, (F, 1))
+        self._complete = True
+        return self
+
+    # ---------------------------------------------------------- results --
+
+    def is_complete(self):
+        return self._complete
+
+    def get_scale_factors(self) -> np.ndarray:
+        """optimize.py:311-345"""
+        if not self._complete:
+            raise Exception('Analysis is still running. Unable to get scale '
+                            + 'factors.')
+        refactors = self._refactors.copy()
+        refactors[refactors == 0] = 1       # bits that were never seen
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', category=RuntimeWarning)
+            return np.nanmedian(
+                np.multiply(refactors, self._previous_factors), axis=0)
+
+    def get_backgrounds(self) -> np.ndarray:
+        """optimize.py:347-378"""
+        if not self._complete:
+            raise Exception('Analysis is still running. Unable to get '
+                            + 'backgrounds.')
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', category=RuntimeWarning)
+            return np.nanmedian(np.add(
+                self._previous_backgrounds,
+                np.multiply(self._bg_refactors, self._previous_factors)),
+                axis=0)
+
+    def get_scale_factor_history(self) -> np.ndarray:
+        """optimize.py:380-395"""
+        if self._previous is None:
+            return np.array([self.get_scale_factors()])
+        return np.append(self._previous.get_scale_factor_history(),
+                         [self.get_scale_factors()], axis=0)
+
+    def get_barcode_count_history(self) -> np.ndarray:
+        """optimize.py:397-416"""
+        countsMean = np.mean(self._counts, axis=0)
+        if self._previous is None:
+            return np.array([countsMean])
+        return np.append(self._previous.get_barcode_count_history(),
+                         [countsMean], axis=0)

@@ -94,3 +94,57 @@ def test_run_fov_matches_drop_in_api(gpu_device):
     exp = pandas.concat([f for f in frames if len(f)])
     assert np.array_equal(frame_to_array(bc, 16), frame_to_array(exp, 16))
     assert np.array_equal(bc.index.to_numpy(), exp.index.to_numpy())
+
+
+def test_optimize_iterations_match_oracle(gpu_device):
+    """Two chained OptimizeIteration passes over the reference test-suite FOVs
+    (test_analysis_parameters.json:17-41: fov_per_iteration 2) against the
+    oracle's decode -> extract_refactors -> nanmedian loop."""
+    import torch
+    from merlin_amd import optimize
+    g = np.load(__import__('os').path.join(
+        __import__('conftest').GOLDEN_DIR, 'testsuite_inputs.npz'))
+    images, cb = g['images'], g['codebook']
+    dm = oracle.normalized_codebook(cb)
+    dev_imgs = [torch.from_numpy(images[f]).to(gpu_device) for f in range(2)]
+    hist = sum(optimize.pixel_histogram(d) for d in dev_imgs)
+    init = optimize.initial_scale_factors(optimize.summed_pixel_histogram(hist))
+    ref_hist = np.array([sum(np.histogram(images[f][b],
+                                          bins=np.arange(0, 65535, 1))[0]
+                             for f in range(2)) for b in range(16)])
+    assert np.array_equal(init, oracle.initial_scale_factors(ref_hist))
+    # the raw frames keep their camera offset: start from a background guess
+    bg0 = np.array([np.median(images[:, b]) for b in range(16)])
+
+    class Warm(object):          # "previous iteration" carrying the start
+        def get_scale_factors(self): return init - bg0
+        def get_backgrounds(self): return bg0
+        def get_scale_factor_history(self): return np.array([init - bg0])
+        def get_barcode_count_history(self): return np.zeros((1, 140))
+
+    frags = [[0, 0], [1, 0]]
+    prev = Warm()
+    sf, bg = init - bg0, bg0
+    for it in range(2):
+        cur = optimize.OptimizeIteration(
+            ArrayCodebook(cb), {'fov_index': frags, 'area_threshold': 3,
+                                'optimize_background': True},
+            previousIteration=prev,
+            imageProvider=lambda f, z: dev_imgs[f], device=gpu_device).run()
+        rfs, bgrs = [], []
+        for f, z in frags:
+            di, pm, npt, d = oracle.decode_pixels(images[f], dm, sf, bg)
+            rf, bgr, seen = oracle.extract_refactors(di, pm, npt, dm, 3, True)
+            rfs.append(rf)
+            bgrs.append(bgr)
+        prevf = np.tile(sf, (2, 1))
+        esf = oracle.reduce_scale_factors(np.array(rfs), prevf)
+        ebg = oracle.reduce_backgrounds(np.array(bgrs), np.tile(bg, (2, 1)),
+                                        prevf)
+        np.testing.assert_allclose(cur.get_scale_factors(), esf, rtol=1e-12,
+                                   equal_nan=True)
+        np.testing.assert_allclose(cur.get_backgrounds(), ebg, rtol=1e-12,
+                                   atol=1e-12, equal_nan=True)
+        assert set(cur.barcodes) == {0, 1}
+        sf, bg, prev = esf, ebg, cur
+    assert cur.get_scale_factor_history().shape == (3, 16)

@@ -1,0 +1,167 @@
+"""CPU: the OptimizeIteration exchange step over torch.distributed (gloo,
+world size 2) and the host reductions, against the oracle's restatement of
+optimize.py:311-378."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import merfish_oracle as oracle
+from conftest import ArrayCodebook, load_golden
+from merlin_amd import optimize
+
+
+def _fake_fragment(decoder, fov, z, sf, bg):
+    """deterministic per-fragment result incl. zeros and NaNs"""
+    rng = np.random.default_rng(1000 * fov + z)
+    rf = rng.uniform(0.5, 1.5, 16)
+    rf[rng.integers(16)] = 0.0
+    if fov % 3 == 0:
+        rf[rng.integers(16)] = np.nan
+    return rf * (sf.mean() / sf.mean()), rng.uniform(-3, 3, 16), \
+        rng.integers(0, 50, 140).astype(float)
+
+
+def _run_two_iterations(group=None):
+    cb = ArrayCodebook(load_golden('g3_edges')['codebook'])
+    frags = [[f, z] for f in range(7) for z in range(1)]
+    init = np.linspace(200, 500, 16)
+    it1 = optimize.OptimizeIteration(
+        cb, {'fov_index': frags, 'optimize_background': True},
+        initialScaleFactors=init, fragmentFunction=_fake_fragment,
+        group=group).run()
+    it2 = optimize.OptimizeIteration(
+        cb, {'fov_index': frags[::-1], 'optimize_background': True},
+        previousIteration=it1, fragmentFunction=_fake_fragment,
+        group=group).run()
+    return it1, it2
+
+
+def _expected():
+    frags = [[f, 0] for f in range(7)]
+    init = np.linspace(200, 500, 16)
+    out = []
+    sf, bg = init, np.zeros(16)
+    for order in (frags, frags[::-1]):
+        res = [_fake_fragment(None, f, z, sf, bg) for f, z in order]
+        rf = np.array([r[0] for r in res])
+        bgr = np.array([r[1] for r in res])
+        prev = np.tile(sf, (len(order), 1))
+        new_sf = oracle.reduce_scale_factors(rf, prev)
+        new_bg = oracle.reduce_backgrounds(bgr, np.tile(bg, (len(order), 1)),
+                                           prev)
+        out.append((new_sf, new_bg, np.mean([r[2] for r in res], axis=0)))
+        sf, bg = new_sf, new_bg
+    return out
+
+
+def test_single_process_matches_oracle():
+    it1, it2 = _run_two_iterations()
+    exp = _expected()
+    assert np.array_equal(it1.get_scale_factors(), exp[0][0], equal_nan=True)
+    assert np.array_equal(it1.get_backgrounds(), exp[0][1], equal_nan=True)
+    assert np.array_equal(it2.get_scale_factors(), exp[1][0], equal_nan=True)
+    assert np.array_equal(it2.get_backgrounds(), exp[1][1], equal_nan=True)
+    hist = it2.get_scale_factor_history()
+    assert hist.shape == (2, 16)
+    assert np.array_equal(hist[0], exp[0][0], equal_nan=True)
+    counts = it2.get_barcode_count_history()
+    assert counts.shape == (2, 140)
+    assert np.array_equal(counts[1], exp[1][2])
+
+
+def test_not_complete_raises():
+    cb = ArrayCodebook(load_golden('g3_edges')['codebook'])
+    it = optimize.OptimizeIteration(cb, {'fov_index': [[0, 0]]},
+                                    initialScaleFactors=np.ones(16),
+                                    fragmentFunction=_fake_fragment)
+    with pytest.raises(Exception):
+        it.get_scale_factors()
+    with pytest.raises(NotImplementedError):
+        optimize.OptimizeIteration(
+            cb, {'optimize_chromatic_correction': True})
+
+
+def test_default_fragment_draw_is_reproducible():
+    cb = ArrayCodebook(load_golden('g3_edges')['codebook'])
+    a = optimize.OptimizeIteration(cb, {'fov_per_iteration': 9},
+                                   fovs=range(20), zCount=7, seed=5)
+    b = optimize.OptimizeIteration(cb, {'fov_per_iteration': 9},
+                                   fovs=range(20), zCount=7, seed=5)
+    assert a.parameters['fov_index'] == b.parameters['fov_index']
+    assert len(a.parameters['fov_index']) == 9 and a.fragment_count() == 9
+    assert all(0 <= f < 20 and 0 <= z < 7 for f, z in a.parameters['fov_index'])
+
+
+def test_shard_fragments():
+    parts = [optimize.shard_fragments(11, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(11))
+    assert parts[1] == [1, 5, 9]
+
+
+def test_initial_scale_factors_and_histogram():
+    g = load_golden('g1_testsuite_fov0')
+    img = torch.from_numpy(g['image'].astype(np.int32)).to(torch.uint16) \
+        if hasattr(torch, 'uint16') else None
+    h = optimize.pixel_histogram(img).numpy()
+    ref = np.array([np.histogram(g['image'][b], bins=np.arange(0, 65535, 1))[0]
+                    for b in range(16)], dtype=np.float64)
+    assert np.array_equal(h, ref)
+    assert np.array_equal(optimize.initial_scale_factors(h),
+                          oracle.initial_scale_factors(ref))
+    edge = torch.tensor([[0, 65533, 65534, 65535, 7]], dtype=torch.int32) \
+        .to(torch.uint16)
+    he = optimize.pixel_histogram(edge).numpy()
+    assert np.array_equal(
+        he[0], np.histogram(np.array([0, 65533, 65534, 65535, 7]),
+                            bins=np.arange(0, 65535, 1))[0])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        it1, it2 = _run_two_iterations()
+        hist = torch.zeros((16, 65534), dtype=torch.float64)
+        hist[:, 10 + rank] = rank + 1.0
+        total = optimize.summed_pixel_histogram(hist)
+        q.put((rank, it1.get_scale_factors(), it1.get_backgrounds(),
+               it2.get_scale_factors(), it2.get_backgrounds(),
+               it2.get_barcode_count_history(), total[:, 8:14]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_matches_single_process():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = _expected()
+    for r in res:
+        assert np.array_equal(r[1], exp[0][0], equal_nan=True)
+        assert np.array_equal(r[2], exp[0][1], equal_nan=True)
+        assert np.array_equal(r[3], exp[1][0], equal_nan=True)
+        assert np.array_equal(r[4], exp[1][1], equal_nan=True)
+        assert np.array_equal(r[5][1], exp[1][2])
+        assert r[6][0].tolist() == [0, 0, 1, 2, 0, 0]
