@@ -38,6 +38,8 @@ extern "C" {
 #define MF_MAX_RADIUS    4   /* blur radius: ksize <= 9, i.e. sigma <= 2    */
 #define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
 
+#define MF_CODEBOOK_UNIFORM 1 /* flag: all codewords share weight and value   */
+
 #define MF_DTYPE_U16     0
 #define MF_DTYPE_F32     1
 #define MF_DTYPE_F64     2
@@ -61,7 +63,8 @@ int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed,
  *               entry of a row must carry the same value; anything else
  *               returns MF_EUNSUPPORTED.
  *   table       device buffer of mf_codebook_table_bytes(N, B) bytes
- * Synchronous (one hipMemcpy); call once per codebook. */
+ * Synchronous (one hipMemcpy); call once per codebook.  Returns the codebook
+ * flags (>= 0, MF_CODEBOOK_*) that mf_decode_pixels takes, or an error. */
 int64_t mf_codebook_table_bytes(int N, int B);
 int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
                         int64_t table_bytes);
@@ -71,6 +74,7 @@ int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
  *   image      u16 (MF_DTYPE_U16) or f32 stack, element (b,z,y,x) at
  *              image[b*img_bit_stride + z*img_z_stride + y*W + x]
  *   codebook_table  device table from mf_codebook_prepare for N codewords
+ *   codebook_flags  the value mf_codebook_prepare returned for that table
  *   h_scale, h_background   host float[B]: scale factors / backgrounds already
  *              rounded to float32 (legacy numpy value casting, decoding.py:103)
  *   decoded    int16 [Z,H,W]   barcode index or -1
@@ -89,7 +93,7 @@ int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
 int mf_decode_pixels(const void *image, int image_dtype,
                      int B, int Z, int H, int W,
                      int64_t img_bit_stride, int64_t img_z_stride,
-                     const void *codebook_table, int N,
+                     const void *codebook_table, int N, int codebook_flags,
                      const float *h_scale, const float *h_background,
                      double sigma, double distance_threshold,
                      float magnitude_threshold,

@@ -57,7 +57,7 @@ def lib():
     L.mf_codebook_prepare.argtypes = [c.POINTER(c.c_double), i32, i32, vp, i64]
     L.mf_decode_pixels.restype = i32
     L.mf_decode_pixels.argtypes = [
-        vp, i32, i32, i32, i32, i32, i64, i64, vp, i32,
+        vp, i32, i32, i32, i32, i32, i64, i64, vp, i32, i32,
         c.POINTER(c.c_float), c.POINTER(c.c_float), f64, f64, f32,
         vp, vp, vp, i32, vp, i64, i64, vp]
     L.mf_label_components.restype = i32

@@ -64,7 +64,7 @@ constexpr int32_t CB_MAGIC = 0x4d464342;   // "MFCB"
 struct DecodeArgs {
     const void *img;
     int64_t bit_stride, z_stride;
-    int B, Z, H, W, N, Npad, fast_ok;
+    int B, Z, H, W, N, Npad, fast_ok, uniform;
     const unsigned char *cbt;          // codebook table blob
     int64_t off_a, off_mask, off_v, off_hn, off_v64;
     float sf[MF_MAX_BITS], bg[MF_MAX_BITS];
@@ -102,7 +102,8 @@ __device__ __forceinline__ void top2_update(Top2 &t, float s, int n)
 {
     t.second = __builtin_amdgcn_fmed3f(t.best, t.second, s);
     t.bi = s > t.best ? n : t.bi;
-    t.best = fmaxf(t.best, s);
+    // max(best, s) as one v_med3 (fmaxf adds a canonicalising v_max first)
+    t.best = __builtin_amdgcn_fmed3f(t.best, s, INFINITY);
 }
 
 // exact float64 squared distance between the normalised trace and codeword
@@ -121,8 +122,15 @@ __device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask
     return d2;
 }
 
-template <typename PIX, int R, int MAXB, int PPT>
-__global__ void __launch_bounds__(NTHREADS, 2)
+#ifndef MF_WAVES_PER_SIMD
+#define MF_WAVES_PER_SIMD 2
+#endif
+#ifndef MF_PPT16
+#define MF_PPT16 4
+#endif
+
+template <typename PIX, int R, int MAXB, int PPT, bool UNI>
+__global__ void __launch_bounds__(NTHREADS, MF_WAVES_PER_SIMD)
 decode_kernel(const DecodeArgs a)
 {
     using HT = typename HType<PIX>::type;
@@ -155,7 +163,6 @@ decode_kernel(const DecodeArgs a)
     const PIX *img = reinterpret_cast<const PIX *>(a.img);
     const uint32_t *g_mask = reinterpret_cast<const uint32_t *>(a.cbt + a.off_mask);
     const double *g_v64 = reinterpret_cast<const double *>(a.cbt + a.off_v64);
-    const int uniform = reinterpret_cast<const CbHeader *>(a.cbt)->uniform;
 
     auto load_chunk = [&](int c0, int cn) {   // cn multiple of 32
         const u32x4 *src = reinterpret_cast<const u32x4 *>(a.cbt + a.off_a + (size_t)c0 * MAXB * 2);
@@ -246,9 +253,10 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int c = RA + j;
-                            uint32_t acc = a.kfix[R] * p[c];
+                            uint32_t acc = __umul24(a.kfix[R], p[c]);
 #pragma unroll
-                            for (int i = 1; i <= R; ++i) acc += a.kfix[R + i] * (p[c - i] + p[c + i]);
+                            for (int i = 1; i <= R; ++i)
+                                acc += __umul24(a.kfix[R + i], p[c - i] + p[c + i]);
                             v[j] = acc;
                         }
                     } else {
@@ -291,13 +299,15 @@ decode_kernel(const DecodeArgs a)
                         if constexpr (IS_U16) {
                             // V = sum k_j * H_j needs 48 bits: split H into 16-bit
                             // halves, two exact u32 sums, out = (V + 2^31) >> 32
-                            uint32_t hi = a.kfix[R] * (col[o + R] >> 16);
-                            uint32_t lo = a.kfix[R] * (col[o + R] & 0xffffu);
+                            // (operands < 2^24: full-rate 24-bit multiplies)
+                            uint32_t hi = __umul24(a.kfix[R], col[o + R] >> 16);
+                            uint32_t lo = __umul24(a.kfix[R], col[o + R] & 0xffffu);
 #pragma unroll
                             for (int j = 1; j <= R; ++j) {
-                                hi += a.kfix[R + j] * ((col[o + R - j] >> 16) + (col[o + R + j] >> 16));
-                                lo += a.kfix[R + j] *
-                                      ((col[o + R - j] & 0xffffu) + (col[o + R + j] & 0xffffu));
+                                hi += __umul24(a.kfix[R + j],
+                                               (col[o + R - j] >> 16) + (col[o + R + j] >> 16));
+                                lo += __umul24(a.kfix[R + j], (col[o + R - j] & 0xffffu) +
+                                                                  (col[o + R + j] & 0xffffu));
                             }
                             v = (float)((hi + (lo >> 16) + 0x8000u) >> 16);
                         } else {
@@ -387,11 +397,13 @@ decode_kernel(const DecodeArgs a)
                     for (int ks = 0; ks < KS; ++ks)
                         af[ks] = *reinterpret_cast<const u32x4 *>(
                             lds_a + ((size_t)(ct + (lane & 31)) * MAXB + 16 * ks + 8 * half) * 2);
+                    // both pixel tiles first, so the second chain of MFMAs
+                    // runs under the first tile's epilogue
+                    f32x16 acc[2];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        f32x16 acc;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.0f;
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -399,32 +411,34 @@ decode_kernel(const DecodeArgs a)
                                 u32x4 bv;
                                 bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
                                 bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                     __builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, bv),
-                                    acc, 0, 0, 0);
+                                    acc[tt], 0, 0, 0);
                             }
-                        // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of
-                        // pixel (lane&31) + 32*tt
+                    }
+                    // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of
+                    // pixel (lane&31) + 32*tt.  Uniform codebooks rank by the raw
+                    // on-bit sum; zero padding rows are caught after the merge.
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
                             const int nl = ct + 8 * gq + 4 * half;
                             float s4[4];
-                            if (uniform) {
+                            if constexpr (UNI) {
 #pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    s4[i] = c0 + nl + i < a.N ? acc[4 * gq + i] : -INFINITY;
+                                for (int i = 0; i < 4; ++i) s4[i] = acc[tt][4 * gq + i];
                             } else {
                                 const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
                                 const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
-                                s4[0] = fmaf(vv.x, acc[4 * gq + 0], -hh.x);
-                                s4[1] = fmaf(vv.y, acc[4 * gq + 1], -hh.y);
-                                s4[2] = fmaf(vv.z, acc[4 * gq + 2], -hh.z);
-                                s4[3] = fmaf(vv.w, acc[4 * gq + 3], -hh.w);
+                                s4[0] = fmaf(vv.x, acc[tt][4 * gq + 0], -hh.x);
+                                s4[1] = fmaf(vv.y, acc[tt][4 * gq + 1], -hh.y);
+                                s4[2] = fmaf(vv.z, acc[tt][4 * gq + 2], -hh.z);
+                                s4[3] = fmaf(vv.w, acc[tt][4 * gq + 3], -hh.w);
                             }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) top2_update(st[tt], s4[i], c0 + nl + i);
                         }
-                    }
                 }
             }
 
@@ -443,10 +457,12 @@ decode_kernel(const DecodeArgs a)
             const float second = fmaxf(fminf(b0, b1), fmaxf(s0, s1));
             int win = b0 > b1 ? i0 : (b1 > b0 ? i1 : min(i0, i1));
             // uniform codebooks compare raw on-bit sums (score / v): widen eps
-            const float eps = uniform ? TIE_EPS * 4.0f : TIE_EPS;
+            const float eps = UNI ? TIE_EPS * 4.0f : TIE_EPS;
 
             double d2 = exact_d2<MAXB>(x[o], g_mask[win], g_v64[win], B);
-            if (best - second < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN) {
+            // a zero padding row can only "win" when every real sum is <= 0
+            if (win >= a.N ||
+                (best - second < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN)) {
                 // ambiguous and possibly within the threshold: exact scan,
                 // lowest index wins exact ties (the oracle's rule)
                 d2 = INFINITY;
@@ -478,7 +494,7 @@ decode_kernel(const DecodeArgs a)
     }
 }
 
-template <typename PIX, int R, int MAXB, int PPT>
+template <typename PIX, int R, int MAXB, int PPT, bool UNI>
 int launch(DecodeArgs &a, hipStream_t stream)
 {
     using HT = typename HType<PIX>::type;
@@ -498,11 +514,11 @@ int launch(DecodeArgs &a, hipStream_t stream)
     const size_t lds = hs_bytes + (size_t)chunk * per_word + 2 * MAXB * sizeof(float);
 
     const int cus = mf::device_cu_count();
-    int64_t grid = (int64_t)cus * 4;
+    int64_t grid = (int64_t)cus * MF_WAVES_PER_SIMD;
     if (grid > nt) grid = nt;
     grid = (grid + 7) & ~int64_t(7);
 
-    auto kern = decode_kernel<PIX, R, MAXB, PPT>;
+    auto kern = decode_kernel<PIX, R, MAXB, PPT, UNI>;
     if (lds > 48 * 1024)
         MF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -514,8 +530,10 @@ int launch(DecodeArgs &a, hipStream_t stream)
 template <typename PIX, int R>
 int dispatch_bits(DecodeArgs &a, hipStream_t s)
 {
-    if (a.B <= 16) return launch<PIX, R, 16, 4>(a, s);
-    return launch<PIX, R, 32, 2>(a, s);
+    if (a.B <= 16)
+        return a.uniform ? launch<PIX, R, 16, MF_PPT16, true>(a, s)
+                         : launch<PIX, R, 16, MF_PPT16, false>(a, s);
+    return a.uniform ? launch<PIX, R, 32, 2, true>(a, s) : launch<PIX, R, 32, 2, false>(a, s);
 }
 
 template <typename PIX>
@@ -620,7 +638,7 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
     h.uniform = uniform;
     std::memcpy(blob.data(), &h, sizeof(h));
     MF_HIP_CHECK(hipMemcpy(table, blob.data(), (size_t)h.total, hipMemcpyHostToDevice));
-    return MF_OK;
+    return uniform ? MF_CODEBOOK_UNIFORM : 0;
 }
 
 extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, float *h_float)
@@ -666,7 +684,8 @@ extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, floa
 
 extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z, int H, int W,
                                 int64_t img_bit_stride, int64_t img_z_stride,
-                                const void *codebook_table, int N, const float *h_scale,
+                                const void *codebook_table, int N, int codebook_flags,
+                                const float *h_scale,
                                 const float *h_background, double sigma,
                                 double distance_threshold, float magnitude_threshold,
                                 int16_t *decoded, float *magnitudes, void *distances,
@@ -703,6 +722,7 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     a.bit_stride = img_bit_stride;
     a.z_stride = img_z_stride;
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.N = N; a.Npad = h.Npad;
+    a.uniform = (codebook_flags & MF_CODEBOOK_UNIFORM) != 0;
     // the 4-byte window loads need even element offsets for u16 rows
     a.fast_ok = image_dtype == MF_DTYPE_F32 ||
                 (!(W & 1) && !((img_bit_stride | img_z_stride) & 1) &&

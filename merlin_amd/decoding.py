@@ -146,7 +146,7 @@ class PixelBasedDecoder(object):
                 table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 cb = np.ascontiguousarray(self._decodingMatrix,
                                           dtype=np.float64)
-                _lib.check(L.mf_codebook_prepare(
+                self._cb_flags = _lib.check(L.mf_codebook_prepare(
                     cb.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), N, B,
                     table.data_ptr(), nbytes))
             self._cb_dev = table
@@ -218,7 +218,7 @@ class PixelBasedDecoder(object):
             _lib.check(L.mf_decode_pixels(
                 imageData.data_ptr(), dt, B, Z, H, W,
                 imageData.stride(0), imageData.stride(1),
-                cb.data_ptr(), self._barcodeCount,
+                cb.data_ptr(), self._barcodeCount, self._cb_flags,
                 sf.ctypes.data_as(fp), bg.ctypes.data_as(fp),
                 float(lowPassSigma), float(distanceThreshold),
                 float(np.float32(magnitudeThreshold)),

@@ -40,7 +40,7 @@ def test_argument_errors_are_reported():
     assert L.mf_gaussian_taps(4, 1.0, fx, None) == -1
     assert b'ksize' in L.mf_last_error_string()
     # null pointers are rejected before any GPU work
-    rc = L.mf_decode_pixels(None, 0, 16, 1, 8, 8, 64, 64, None, 1, None, None,
+    rc = L.mf_decode_pixels(None, 0, 16, 1, 8, 8, 64, 64, None, 1, 0, None, None,
                             1.0, 0.5, 1.0, None, None, None, 1, None, 0, 0,
                             None)
     assert rc == -1
