@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -42,7 +43,10 @@ namespace {
 
 constexpr int TW = 64;              // tile width  = wave width
 constexpr int NTHREADS = 256;       // 4 waves
-constexpr int GROUP = 4;            // bits staged per barrier pair
+#ifndef MF_GROUP
+#define MF_GROUP 4
+#endif
+constexpr int GROUP = MF_GROUP;     // bits staged per barrier pair
 #ifndef MF_TIE_EPS
 #define MF_TIE_EPS 1.0e-5f
 #endif
@@ -64,7 +68,7 @@ constexpr int32_t CB_MAGIC = 0x4d464342;   // "MFCB"
 struct DecodeArgs {
     const void *img;
     int64_t bit_stride, z_stride;
-    int B, Z, H, W, N, Npad, fast_ok, uniform;
+    int B, Z, H, W, N, Npad, fast_ok, uniform, fast_div;
     const unsigned char *cbt;          // codebook table blob
     int64_t off_a, off_mask, off_v, off_hn, off_v64;
     float sf[MF_MAX_BITS], bg[MF_MAX_BITS];
@@ -87,7 +91,9 @@ __device__ __forceinline__ int reflect101(int i, int n)
 {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * n - 2 - i;
-    return i;
+    // a tile may overhang the image by more than the blur radius: those
+    // positions feed no real pixel, they only have to stay inside the image
+    return min(max(i, 0), n - 1);
 }
 
 template <typename PIX> struct HType { using type = uint32_t; };
@@ -104,6 +110,20 @@ __device__ __forceinline__ void top2_update(Top2 &t, float s, int n)
     t.bi = s > t.best ? n : t.bi;
     // max(best, s) as one v_med3 (fmaxf adds a canonicalising v_max first)
     t.best = __builtin_amdgcn_fmed3f(t.best, s, INFINITY);
+}
+
+// Correctly rounded n / d from the correctly rounded reciprocal r = RN(1/d):
+// q0 = RN(n r) is within ~1 ulp, one residual step makes it faithful, and by
+// Markstein's theorem a second residual step on a faithful quotient with a
+// correctly rounded reciprocal returns RN(n / d) (no over/underflow here: the
+// host only enables this path for 2^-60 < |d| < 2^60).  5 ops instead of the
+// ~13-op IEEE division sequence.
+__device__ __forceinline__ float div_by_recip(float n, float d, float r)
+{
+    float q = n * r;
+    q = fmaf(fmaf(-q, d, n), r, q);
+    q = fmaf(fmaf(-q, d, n), r, q);
+    return q;
 }
 
 // exact float64 squared distance between the normalised trace and codeword
@@ -153,6 +173,7 @@ decode_kernel(const DecodeArgs a)
     float *lds_hn = lds_v + a.chunk;
     float *lds_sf = lds_hn + a.chunk;                                // [MAXB] scale factors
     float *lds_bg = lds_sf + MAXB;                                   // [MAXB] backgrounds
+    float *lds_rs = lds_bg + MAXB;                                   // [MAXB] RN(1 / scale)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -177,6 +198,7 @@ decode_kernel(const DecodeArgs a)
     if (tid < MAXB) {
         lds_sf[tid] = tid < B ? a.sf[tid] : 1.0f;
         lds_bg[tid] = tid < B ? a.bg[tid] : 0.0f;
+        lds_rs[tid] = tid < B ? 1.0f / a.sf[tid] : 1.0f;     // IEEE division
     }
 
     // XCD-aware tile walk: blocks with the same (blockIdx % 8) share an XCD
@@ -288,7 +310,7 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                 for (int i = 0; i < GROUP; ++i) {
                     const int b = g * GROUP + i;
-                    const float sfb = lds_sf[b], bgb = lds_bg[b];
+                    const float sfb = lds_sf[b], bgb = lds_bg[b], rsb = lds_rs[b];
                     HT col[PPT + 2 * R];
 #pragma unroll
                     for (int j = 0; j < PPT + 2 * R; ++j)
@@ -317,7 +339,8 @@ decode_kernel(const DecodeArgs a)
                                 acc = acc + a.kflt[R + j] * (col[o + R - j] + col[o + R + j]);
                             v = acc;
                         }
-                        x[o][b] = b < B ? (v - bgb) / sfb : 0.0f;
+                        x[o][b] = b >= B ? 0.0f : a.fast_div ? div_by_recip(v - bgb, sfb, rsb)
+                                                            : (v - bgb) / sfb;
                     }
                 }
                 __syncthreads();   // hs is rewritten by the next group
@@ -339,8 +362,17 @@ decode_kernel(const DecodeArgs a)
             float m = sqrtf(acc);
             if (m == 0.0f) m = 1.0f;
             mag[o] = m;
+#ifndef MF_ABL_NONORM
+            // m >= 2^-60 or exactly 1 whenever fast_div is set (see host)
+            if (a.fast_div && m > 0x1p-60f && m < 0x1p60f) {
+                const float rm = 1.0f / m;
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) x[o][b] = x[o][b] / m;
+                for (int b = 0; b < MAXB; ++b) x[o][b] = div_by_recip(x[o][b], m, rm);
+            } else {
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) x[o][b] = x[o][b] / m;
+            }
+#endif
         }
 
         // ---- nearest codeword on the matrix cores, one pixel row at a time ----
@@ -383,7 +415,11 @@ decode_kernel(const DecodeArgs a)
                     }
             }
 
+#ifdef MF_ABL_NONN
+            for (int c0 = 0; c0 < 0; c0 += a.chunk) {
+#else
             for (int c0 = 0; c0 < a.Npad; c0 += a.chunk) {
+#endif
                 const int cn = min(a.chunk, a.Npad - c0);
                 if (!single_chunk) {
                     __syncthreads();            // previous chunk fully consumed
@@ -459,7 +495,11 @@ decode_kernel(const DecodeArgs a)
             // uniform codebooks compare raw on-bit sums (score / v): widen eps
             const float eps = UNI ? TIE_EPS * 4.0f : TIE_EPS;
 
+#ifdef MF_ABL_NOF64
+            double d2 = (double)(2.0f - best);
+#else
             double d2 = exact_d2<MAXB>(x[o], g_mask[win], g_v64[win], B);
+#endif
             // a zero padding row can only "win" when every real sum is <= 0
             if (win >= a.N ||
                 (best - second < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN)) {
@@ -474,7 +514,11 @@ decode_kernel(const DecodeArgs a)
             const double d = sqrt(d2);
 
             const int gy = y0 + wave * PPT + o, gx = x0 + lane;
+#ifdef MF_ABL_NOSTORE
+            if (gy < H && gx < W && d == 12345.0) {
+#else
             if (gy < H && gx < W) {
+#endif
                 const int64_t pix = ((int64_t)z * H + gy) * W + gx;
                 int16_t code = d <= a.dthr ? (int16_t)win : (int16_t)-1;
                 if (mag[o] < a.mthr) code = -1;
@@ -508,13 +552,17 @@ int launch(DecodeArgs &a, hipStream_t stream)
     const size_t hs_bytes = (size_t)GROUP * RH * TW * sizeof(HT);
     const size_t per_word = (size_t)MAXB * 2 + 8;
     const size_t budget = 96 * 1024;
-    int chunk = (int)((budget - hs_bytes - 256) / per_word) & ~31;
+    int chunk = (int)((budget - hs_bytes - 384) / per_word) & ~31;
     if (chunk > a.Npad) chunk = a.Npad;
     a.chunk = chunk;
-    const size_t lds = hs_bytes + (size_t)chunk * per_word + 2 * MAXB * sizeof(float);
+    const size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * sizeof(float);
 
     const int cus = mf::device_cu_count();
-    int64_t grid = (int64_t)cus * MF_WAVES_PER_SIMD;
+    // far more workgroups than resident slots: the dispatcher balances the
+    // CUs much better than an exactly-resident persistent grid (measured:
+    // 2.86 ms at 2 WGs/CU vs 2.19 ms at 32 WGs/CU for one 7-z FOV)
+    int64_t grid = (int64_t)cus * 32;
+    if (const char *gm = std::getenv("MF_GRID_MULT")) grid = (int64_t)cus * std::atoi(gm);   // tuning aid
     if (grid > nt) grid = nt;
     grid = (grid + 7) & ~int64_t(7);
 
@@ -730,7 +778,14 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     a.cbt = reinterpret_cast<const unsigned char *>(codebook_table);
     a.off_a = h.off_a; a.off_mask = h.off_mask; a.off_v = h.off_v; a.off_hn = h.off_hn;
     a.off_v64 = h.off_v64;
-    for (int b = 0; b < B; ++b) { a.sf[b] = h_scale[b]; a.bg[b] = h_background[b]; }
+    a.fast_div = 1;
+    for (int b = 0; b < B; ++b) {
+        a.sf[b] = h_scale[b];
+        a.bg[b] = h_background[b];
+        const float s_abs = std::fabs(h_scale[b]);
+        if (!(s_abs > 0x1p-60f && s_abs < 0x1p60f) || !(std::fabs(h_background[b]) < 0x1p60f))
+            a.fast_div = 0;      // odd scale factors: plain IEEE division
+    }
     int rc = mf_gaussian_taps(ksize, sigma, a.kfix, a.kflt);
     if (rc) return rc;
     a.dthr = distance_threshold;

@@ -159,3 +159,30 @@ def test_cached_device_path_equals_upload_path(gpu_device):
     b = dec2.extract_barcodes_with_index(5, di.copy(), pm.copy(), npt.copy(),
                                          d.copy(), 0, 0, 0)
     assert a.equals(b)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_decode_random_scale_factors(seed, gpu_device):
+    """Bit-exactness of the reciprocal-based division path (and of the plain
+    IEEE path for extreme scale factors) over awkward scale/background values,
+    odd image sizes (edge tiles, unaligned rows) and every blur radius."""
+    from conftest import synth_stack
+    from merlin_amd.decoding import PixelBasedDecoder
+    rng = np.random.default_rng(100 + seed)
+    cb = load_golden('g2_synth192')['codebook']
+    shape = [(70, 130), (64, 64), (33, 77), (128, 66), (17, 200), (96, 96)][seed]
+    img = synth_stack(cb, shape, 25, seed=seed, amp=(500, 60000), bg=50)
+    sf = np.exp(rng.uniform(np.log(0.3), np.log(3e4), 16))
+    bg = rng.uniform(-20, 120, 16)
+    sigma = [1, 0.5, 1.5, 2, 0, 1][seed]
+    if seed == 5:
+        sf[3] = 1e25          # disables the reciprocal path for the launch
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.5176, 1, sigma)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(img, dm, sf, bg, 0.5176, 1,
+                                                   sigma, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert_distances(d, od, gap, odi)
