@@ -25,8 +25,11 @@ constexpr int NT = 256;
 
 __device__ __forceinline__ int ld_label(const int32_t *L, int i)
 {
-    // agent-scope load: parents are updated by atomics from other XCDs
-    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A relaxed load that the compiler may not cache in a register.  A stale
+    // value (another XCD linked the node meanwhile) is harmless: labels only
+    // ever decrease and every link is made by an atomicMin whose return value
+    // is checked, so a stale "root" just costs another round in unite().
+    return __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __device__ __forceinline__ int find_root(const int32_t *L, int x)
@@ -61,20 +64,27 @@ ccl_init(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int n)
 __global__ void __launch_bounds__(NT)
 ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int Z, int H, int W, int conn3d)
 {
-    const int n = Z * H * W;
+    const int total = Z * H * W;
     const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= n) return;
+    if (i >= total) return;
     const int16_t code = dec[i];
     if (code < 0) return;
     const int x = i % W;
     const int y = (i / W) % H;
     const int z = i / (W * H);
-    // same plane: W, NW, N, NE
-    if (x > 0 && dec[i - 1] == code) unite(L, i, i - 1);
-    if (y > 0) {
-        if (x > 0 && dec[i - W - 1] == code) unite(L, i, i - W - 1);
-        if (dec[i - W] == code) unite(L, i, i - W);
-        if (x + 1 < W && dec[i - W + 1] == code) unite(L, i, i - W + 1);
+    // same plane, backward neighbours W, NW, N, NE.  If N matches, W / NW /
+    // NE are 8-adjacent to N and get united with it by their own threads, so
+    // one union suffices; likewise W is adjacent to NW.
+    const bool w = x > 0 && dec[i - 1] == code;
+    const bool n = y > 0 && dec[i - W] == code;
+    const bool nw = y > 0 && x > 0 && dec[i - W - 1] == code;
+    const bool ne = y > 0 && x + 1 < W && dec[i - W + 1] == code;
+    if (n) {
+        unite(L, i, i - W);
+    } else {
+        if (nw) unite(L, i, i - W - 1);
+        else if (w) unite(L, i, i - 1);
+        if (ne) unite(L, i, i - W + 1);
     }
     if (conn3d && z > 0) {
         const int base = i - W * H;

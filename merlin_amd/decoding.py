@@ -116,7 +116,6 @@ class PixelBasedDecoder(object):
         self._device = torch.device(device) if device is not None else None
         self._cb_dev = None
         self._recent = []       # [(weakrefs of returned arrays, DecodedVolume)]
-        self._pin = {}
 
     # ------------------------------------------------------------ helpers --
 
@@ -424,14 +423,13 @@ class PixelBasedDecoder(object):
             cols[c] = inten[:, i]
         return pandas.DataFrame(cols, index=pos[sel], copy=False)
 
-    def _pinned(self, name, shape, dtype):
-        """Reusable page-locked staging buffer (D2H at full PCIe rate)."""
-        n = int(np.prod(shape))
-        buf = self._pin.get(name)
-        if buf is None or buf.numel() < n or buf.dtype != dtype:
-            buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
-            self._pin[name] = buf
-        return buf[:n].view(shape)
+    @staticmethod
+    def _pinned(shape, dtype):
+        """Fresh page-locked staging tensor from torch's caching host
+        allocator (no hipHostMalloc after warm-up).  The numpy views handed to
+        pandas keep it alive, so the DataFrame owns its memory without a
+        second copy."""
+        return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
 
     def _frame_on_device(self, table: RegionTable, is3D, bitCount, fov,
                          cropWidth, globalAligner, minimumArea, cropShape
@@ -465,13 +463,13 @@ class PixelBasedDecoder(object):
                 rec[sel, zcol], (ar - start)[sel].to(torch.float64)])
             out32 = table.inten_d[sel].t().contiguous()
             m = out64.shape[1]
-            h64 = self._pinned('frame64', out64.shape, torch.float64)
-            h32 = self._pinned('frame32', out32.shape, torch.float32)
+            h64 = self._pinned(out64.shape, torch.float64)
+            h32 = self._pinned(out32.shape, torch.float32)
             h64.copy_(out64, non_blocking=True)
             h32.copy_(out32, non_blocking=True)
             torch.cuda.current_stream(dev).synchronize()
-        a64 = h64.numpy().copy()
-        a32 = h32.numpy().copy()
+        a64 = h64.numpy()
+        a32 = h32.numpy()
         xs, ys, zs = a64[6], a64[7], a64[8]
         if globalAligner is not None:
             centroids = np.stack([zs, xs, ys], axis=1)
