@@ -168,35 +168,68 @@ struct StatsArgs {
     float *inten, *mean_tm, *min_tm;
 };
 
-// 16 lanes per region: every lane walks the region's pixels (raster order) and
-// owns the bits sub, sub+16; the scalar statistics are computed redundantly
-// by the 16 lanes (same addresses, broadcast loads) and written by lane 0.
+// 16 lanes per region.  The region's pixels are fetched 16 at a time, one per
+// lane (independent, mostly coalesced loads), and handed round with width-16
+// shuffles, so the float sums still run in the reference's sequential raster
+// order but the memory latency is paid once per 16 pixels instead of once per
+// pixel.  Lane `sub` owns bits sub, sub+16; the scalar statistics are computed
+// redundantly by the 16 lanes and written by lane 0.
 constexpr int RSUB = 16;
 
 __global__ void __launch_bounds__(NT)
 region_stats(const StatsArgs a)
 {
-    const int64_t r = ((int64_t)blockIdx.x * NT + threadIdx.x) / RSUB;
+    int64_t r = ((int64_t)blockIdx.x * NT + threadIdx.x) / RSUB;
     const int sub = threadIdx.x & (RSUB - 1);
-    if (r >= a.n_reg) return;
+    const bool valid = r < a.n_reg;
+    if (!valid) r = a.n_reg - 1;          // keep all 16 lanes in the shuffles
     const int64_t i0 = a.offsets[r];
     const int64_t i1 = r + 1 < a.n_reg ? a.offsets[r + 1] : a.n_pix;
     const int n = (int)(i1 - i0);
     const int plane = a.H * a.W;
     const int first = a.pix[i0];
+    const bool want_tm = a.mean_tm || a.min_tm;
 
-    // pass 1: magnitude sum / max, distance sum / min
+    // pass 1: magnitude sum / max, distance sum / min; per-bit sums
     double msum = 0.0, dsum = 0.0, dmin = INFINITY;
     float mmax = -INFINITY;
-    for (int64_t i = i0; i < i1; ++i) {
-        const int p = a.pix[i];
-        const float m = a.mag[p];
-        msum += (double)m;
-        mmax = fmaxf(mmax, m);
-        const double d = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[p]
-                                    : (double)reinterpret_cast<const float *>(a.dist)[p];
-        dsum += d;
-        dmin = fmin(dmin, d);
+    float s0 = 0.0f, stm0 = 0.0f, mn0 = INFINITY;     // bit sub
+    float s1 = 0.0f, stm1 = 0.0f, mn1 = INFINITY;     // bit sub + 16
+    const bool has0 = sub < a.B, has1 = sub + RSUB < a.B;
+    for (int64_t base = i0; base < i1; base += RSUB) {
+        const int cnt = (int)min((int64_t)RSUB, i1 - base);
+        const int myp = sub < cnt ? a.pix[base + sub] : first;
+        const float mym = a.mag[myp];
+        const double myd = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[myp]
+                                      : (double)reinterpret_cast<const float *>(a.dist)[myp];
+        // issue this lane's trace loads for the whole chunk first
+        float t0[RSUB], t1[RSUB];
+#pragma unroll
+        for (int k = 0; k < RSUB; ++k) {
+            const int p = __shfl(myp, k, RSUB);
+            const int zz = p / plane;
+            const int64_t off = (int64_t)zz * a.tr_z + (p - zz * plane);
+            t0[k] = has0 && k < cnt ? a.traces[off + (int64_t)sub * a.tr_b] : 0.0f;
+            t1[k] = has1 && k < cnt ? a.traces[off + (int64_t)(sub + RSUB) * a.tr_b] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < RSUB; ++k) {
+            const float m = __shfl(mym, k, RSUB);
+            const double d = __shfl(myd, k, RSUB);
+            if (k < cnt) {
+                msum += (double)m;
+                mmax = fmaxf(mmax, m);
+                dsum += d;
+                dmin = fmin(dmin, d);
+                s0 = s0 + t0[k];
+                s1 = s1 + t1[k];
+                if (want_tm) {
+                    const float tm0 = t0[k] * m, tm1 = t1[k] * m;
+                    stm0 = stm0 + tm0; mn0 = fminf(mn0, tm0);
+                    stm1 = stm1 + tm1; mn1 = fminf(mn1, tm1);
+                }
+            }
+        }
     }
     // pass 2: magnitude-weighted centroid
     double cz, cy, cx;
@@ -204,14 +237,24 @@ region_stats(const StatsArgs a)
         cz = first / plane; cy = (first % plane) / a.W; cx = first % a.W;
     } else {
         cz = cy = cx = 0.0;
-        for (int64_t i = i0; i < i1; ++i) {
-            const int p = a.pix[i];
-            const double w = (double)a.mag[p] / msum;
-            cz += (double)(p / plane) * w;
-            cy += (double)((p % plane) / a.W) * w;
-            cx += (double)(p % a.W) * w;
+        for (int64_t base = i0; base < i1; base += RSUB) {
+            const int cnt = (int)min((int64_t)RSUB, i1 - base);
+            const int myp = sub < cnt ? a.pix[base + sub] : first;
+            const float mym = a.mag[myp];
+#pragma unroll
+            for (int k = 0; k < RSUB; ++k) {
+                const int p = __shfl(myp, k, RSUB);
+                const float m = __shfl(mym, k, RSUB);
+                if (k < cnt) {
+                    const double w = (double)m / msum;
+                    cz += (double)(p / plane) * w;
+                    cy += (double)((p % plane) / a.W) * w;
+                    cx += (double)(p % a.W) * w;
+                }
+            }
         }
     }
+    if (!valid) return;
     double mean_int = msum / n, mean_d = n > 1 ? dsum / n : dsum;
     if (a.conn3d) mean_int = (double)(float)mean_int;        // regionprops: f32
     if (a.conn3d && !a.dist_f64) mean_d = (double)(float)mean_d;
@@ -232,25 +275,17 @@ region_stats(const StatsArgs a)
         row[10] = (double)first;
         row[11] = 0.0;
     }
-
     // per-bit means: sequential float32 sums in raster order, then / n
     // (np.mean(list of f32 rows, axis 0), decoding.py:197, 220, 330)
-    for (int b = sub; b < a.B; b += RSUB) {
-        float s = 0.0f, stm = 0.0f, mn = INFINITY;
-        for (int64_t i = i0; i < i1; ++i) {
-            const int p = a.pix[i];
-            const int zz = p / plane;
-            const float t = a.traces[(int64_t)zz * a.tr_z + (int64_t)b * a.tr_b + (p - zz * plane)];
-            s = s + t;
-            if (a.mean_tm || a.min_tm) {
-                const float tm = t * a.mag[p];
-                stm = stm + tm;
-                mn = fminf(mn, tm);
-            }
-        }
-        a.inten[r * a.B + b] = n > 1 ? s / (float)n : s;
-        if (a.mean_tm) a.mean_tm[r * a.B + b] = stm / (float)n;
-        if (a.min_tm) a.min_tm[r * a.B + b] = mn;
+    if (has0) {
+        a.inten[r * a.B + sub] = n > 1 ? s0 / (float)n : s0;
+        if (a.mean_tm) a.mean_tm[r * a.B + sub] = stm0 / (float)n;
+        if (a.min_tm) a.min_tm[r * a.B + sub] = mn0;
+    }
+    if (has1) {
+        a.inten[r * a.B + sub + RSUB] = n > 1 ? s1 / (float)n : s1;
+        if (a.mean_tm) a.mean_tm[r * a.B + sub + RSUB] = stm1 / (float)n;
+        if (a.min_tm) a.min_tm[r * a.B + sub + RSUB] = mn1;
     }
 }
 

@@ -453,8 +453,9 @@ class PixelBasedDecoder(object):
             ar = torch.arange(n, device=dev)
             first = torch.ones(n, dtype=torch.bool, device=dev)
             first[1:] = gkey[1:] != gkey[:-1]
-            start = torch.cummax(torch.where(first, ar, torch.zeros_like(ar)),
-                                 0).values
+            # start row of each (plane, barcode) group, spread to its rows
+            start = torch.nonzero(first).squeeze(1)[
+                torch.cumsum(first.to(torch.int32), 0) - 1]
             sel = torch.nonzero(keep).squeeze(1)
             zcol = 7 if is3D else 1
             out64 = torch.stack([
