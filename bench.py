@@ -86,6 +86,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist_on = world > 1
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:
@@ -160,6 +161,13 @@ def main():
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     del v
 
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc
+    # passes, see profiles/README.md); bench.py cannot read PMCs itself
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'decode_traffic.json')
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+
     if rank == 0:
         mpx = world * args.steps * px_fov / dt / 1e6
         out = {
@@ -182,7 +190,7 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'kernel': 'decode_kernel<u16,R=2,B<=16>',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'kernel_ms': k_ms, 'algorithmic_bytes': alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -186,3 +186,59 @@ def test_decode_random_scale_factors(seed, gpu_device):
     assert np.array_equal(npt, onpt)
     assert np.array_equal(di, odi)
     assert_distances(d, od, gap, odi)
+
+
+@pytest.mark.parametrize('case', ['b22_mhd4', 'b22_n1000_w4', 'b32_n3000_w4',
+                                  'b32_n1500_mixed', 'b12_n1'])
+def test_large_and_odd_codebooks(case, gpu_device):
+    """BASELINE configs 3 and 5 at oracle-sized images: 22-bit codebooks (MHD4,
+    and 1000 distinct weight-4 words: one LDS chunk), 32-bit codebooks that exceed the LDS
+    budget and stream through it in chunks (uniform weight and mixed weight),
+    and the degenerate one-codeword codebook."""
+    from conftest import synth_stack
+    from merlin_amd.codebook import (constant_weight_codebook,
+                                     random_weight_codebook)
+    from merlin_amd.decoding import PixelBasedDecoder
+    rng = np.random.default_rng(11)
+    if case == 'b22_mhd4':
+        # a 22-bit weight-4 code with Hamming distance 4 has at most
+        # C(22,3)/4 = 385 words; the greedy construction finds 263
+        cb = constant_weight_codebook(22, 4, 4).get_barcodes()
+        assert cb.shape[0] >= 200
+    elif case == 'b22_n1000_w4':
+        cb = random_weight_codebook(22, 1000, 4, seed=7).get_barcodes()
+    elif case == 'b32_n3000_w4':
+        cb = random_weight_codebook(32, 3000, 4, seed=11).get_barcodes()
+    elif case == 'b32_n1500_mixed':
+        cb = np.zeros((1500, 32), dtype=np.int64)
+        for i in range(1500):
+            cb[i, rng.choice(32, rng.integers(2, 7), replace=False)] = 1
+        cb = np.unique(cb, axis=0)
+    else:
+        cb = np.zeros((1, 12), dtype=np.int64)
+        cb[0, [1, 4, 7, 9]] = 1
+    N, B = cb.shape
+    img = synth_stack(cb, (48, 80), 40, seed=7)
+    sf = rng.uniform(200, 600, B)
+    bg = rng.uniform(50, 120, B)
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    thr = 0.5176 if case != 'b32_n1500_mixed' else 0.45
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, thr, 1, 1)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(img, dm, sf, bg, thr, 1, 1,
+                                                   return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert (odi >= 0).sum() > 50
+    assert_distances(d, od, gap, odi)
+    # the region table of the decoded image, against the oracle
+    i = int(np.bincount(odi[odi >= 0]).argmax())
+    got = dec.extract_barcodes_with_index(i, di, pm, npt, d, 0, 0, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        exp = oracle.extract_barcodes_with_index(i, odi, opm, onpt, od, 0, 0, 0)
+    r, e = frame_to_array(got, B), frame_to_array(exp, B)
+    assert r.shape == e.shape
+    np.testing.assert_allclose(r[:, :14], e[:, :14], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(r[:, 14:], e[:, 14:])
