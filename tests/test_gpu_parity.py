@@ -242,3 +242,48 @@ def test_large_and_odd_codebooks(case, gpu_device):
     assert r.shape == e.shape
     np.testing.assert_allclose(r[:, :14], e[:, :14], rtol=1e-12, atol=1e-12)
     assert np.array_equal(r[:, 14:], e[:, 14:])
+
+
+@pytest.mark.parametrize('sigma', [0, 0.5, 1, 1.5, 2])
+def test_float_input_path(sigma, gpu_device):
+    """Non-uint16 input is blurred in float32 (cv2's float path; parity with
+    cv2 itself is unpinned, the oracle fixes the operation order).  Also runs
+    every blur radius through an odd-sized image."""
+    from conftest import synth_stack
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    rng = np.random.default_rng(int(sigma * 10))
+    img = synth_stack(cb, (75, 141), 30, seed=3).astype(np.float64)
+    img += rng.uniform(0, 1, img.shape)            # genuinely fractional
+    sf = rng.uniform(200, 600, 16)
+    bg = rng.uniform(50, 120, 16)
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.5176, 1, sigma)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(
+        img.astype(np.float32), dm, sf, bg, 0.5176, 1, sigma, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert_distances(d, od, gap, odi)
+
+
+def test_argument_errors(gpu_device):
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    img = np.zeros((16, 32, 32), dtype=np.uint16)
+    with pytest.raises(ValueError):
+        dec.decode_pixels(img[:15])                      # wrong bit count
+    with pytest.raises(ValueError):
+        dec.decode_pixels(img, scaleFactors=np.ones(3))
+    with pytest.raises(NotImplementedError):
+        dec.decode_pixels(img, lowPassSigma=5)           # ksize 21 > 9
+    with pytest.raises(ValueError):
+        dec.decode_pixels(np.zeros((16, 2, 2), dtype=np.uint16))
+    bad = cb.astype(np.float64)
+    bad[0, 0] = 2                                        # not binary
+    with pytest.raises(NotImplementedError):
+        PixelBasedDecoder(ArrayCodebook(bad), device=gpu_device).decode_pixels(img)
+    with pytest.raises(NotImplementedError):
+        PixelBasedDecoder(ArrayCodebook(np.ones((3, 40), dtype=int)))
