@@ -60,7 +60,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // Device codebook table built by mf_codebook_prepare (offsets in bytes from
 // the start of the blob, 256-byte aligned; a function of N and B only).
 struct CbHeader {
-    int32_t magic, N, B, Npad, KB, uniform, pad0, pad1;
+    int32_t magic, N, B, Npad, KB, uniform;
+    float key_c, pad1;
     int64_t off_a, off_mask, off_v, off_hn, off_v64, off_cb64, total;
 };
 constexpr int32_t CB_MAGIC = 0x4d464342;   // "MFCB"
@@ -99,17 +100,32 @@ __device__ __forceinline__ int reflect101(int i, int n)
 template <typename PIX> struct HType { using type = uint32_t; };
 template <> struct HType<float> { using type = float; };
 
+// Running two smallest codeword keys of one pixel.  A key is half the squared
+// distance to the codeword up to a per-codebook positive factor (see the tile
+// loop), so it is >= 0 and its float bits order like a signed integer; the low
+// 4 bits carry the accumulator slot it came from (a relative perturbation of
+// < 2^-19, i.e. the key keeps its *relative* precision where it matters, at
+// small distances) and the 32-codeword tile is recorded whenever the smallest
+// key changes.  Two keys per step: min3 / med3 / min.
 struct Top2 {
-    float best, second;
-    int bi;
+    int best, second, tile;
 };
+constexpr int KEY_SLOT_MASK = 15;
+constexpr int KEY_INIT = 0x7f7fffff;     // FLT_MAX
 
-__device__ __forceinline__ void top2_update(Top2 &t, float s, int n)
+__device__ __forceinline__ int score_key(float s, int slot)
 {
-    t.second = __builtin_amdgcn_fmed3f(t.best, t.second, s);
-    t.bi = s > t.best ? n : t.bi;
-    // max(best, s) as one v_med3 (fmaxf adds a canonicalising v_max first)
-    t.best = __builtin_amdgcn_fmed3f(t.best, s, INFINITY);
+    return (__float_as_int(s) & ~KEY_SLOT_MASK) | slot;
+}
+
+__device__ __forceinline__ void top2_update2(Top2 &t, int k1, int k2)
+{
+    // v_med3_f32 orders non-negative floats like the integers (a key that
+    // rounding made slightly negative is the winner either way)
+    const int m = __float_as_int(__builtin_amdgcn_fmed3f(
+        __int_as_float(t.best), __int_as_float(k1), __int_as_float(k2)));
+    t.best = min(min(t.best, k1), k2);
+    t.second = min(t.second, m);
 }
 
 // Correctly rounded n / d from the correctly rounded reciprocal r = RN(1/d):
@@ -184,6 +200,7 @@ decode_kernel(const DecodeArgs a)
     const PIX *img = reinterpret_cast<const PIX *>(a.img);
     const uint32_t *g_mask = reinterpret_cast<const uint32_t *>(a.cbt + a.off_mask);
     const double *g_v64 = reinterpret_cast<const double *>(a.cbt + a.off_v64);
+    const float key_c = reinterpret_cast<const CbHeader *>(a.cbt)->key_c;
 
     auto load_chunk = [&](int c0, int cn) {   // cn multiple of 32
         const u32x4 *src = reinterpret_cast<const u32x4 *>(a.cbt + a.off_a + (size_t)c0 * MAXB * 2);
@@ -384,7 +401,7 @@ decode_kernel(const DecodeArgs a)
             Top2 st[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                st[tt].best = -INFINITY; st[tt].second = -INFINITY; st[tt].bi = 0;
+                st[tt].best = KEY_INIT; st[tt].second = KEY_INIT; st[tt].tile = 0;
             }
             uint32_t pk[3][KS][8];
 #pragma unroll
@@ -438,8 +455,12 @@ decode_kernel(const DecodeArgs a)
                     f32x16 acc[2];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
+                        // the table entries are -t (t = 1, or 1/2 above 16 bits),
+                        // so acc = start - t * (sum of the on bits).  Uniform
+                        // codebooks start at key_c >= t * sqrt(weight) >= t * sum:
+                        // the accumulator is the key, key = d^2 / (2 v / t)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.0f;
+                        for (int i = 0; i < 16; ++i) acc[tt][i] = UNI ? key_c : 0.0f;
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -453,56 +474,67 @@ decode_kernel(const DecodeArgs a)
                             }
                     }
                     // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of
-                    // pixel (lane&31) + 32*tt.  Uniform codebooks rank by the raw
-                    // on-bit sum; zero padding rows are caught after the merge.
+                    // pixel (lane&31) + 32*tt in accumulator slot i.  Zero
+                    // padding rows of a uniform table are caught after the merge.
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
+                    for (int tt = 0; tt < 2; ++tt) {
+                        const int before = st[tt].best;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            const int nl = ct + 8 * gq + 4 * half;
                             float s4[4];
                             if constexpr (UNI) {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) s4[i] = acc[tt][4 * gq + i];
                             } else {
+                                // (1 + |c|^2) / 2 - v * sum = d^2 / 2
+                                const int nl = ct + 8 * gq + 4 * half;
                                 const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
                                 const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
-                                s4[0] = fmaf(vv.x, acc[tt][4 * gq + 0], -hh.x);
-                                s4[1] = fmaf(vv.y, acc[tt][4 * gq + 1], -hh.y);
-                                s4[2] = fmaf(vv.z, acc[tt][4 * gq + 2], -hh.z);
-                                s4[3] = fmaf(vv.w, acc[tt][4 * gq + 3], -hh.w);
+                                s4[0] = fmaf(vv.x, acc[tt][4 * gq + 0], hh.x);
+                                s4[1] = fmaf(vv.y, acc[tt][4 * gq + 1], hh.y);
+                                s4[2] = fmaf(vv.z, acc[tt][4 * gq + 2], hh.z);
+                                s4[3] = fmaf(vv.w, acc[tt][4 * gq + 3], hh.w);
                             }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) top2_update(st[tt], s4[i], c0 + nl + i);
+                            top2_update2(st[tt], score_key(s4[0], 4 * gq + 0),
+                                         score_key(s4[1], 4 * gq + 1));
+                            top2_update2(st[tt], score_key(s4[2], 4 * gq + 2),
+                                         score_key(s4[3], 4 * gq + 3));
                         }
+                        st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
+                    }
                 }
             }
 
             // ---- merge lane halves, exact float64 distance, thresholds ----
             // after the swaps both states in a lane belong to its own pixel
-            auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].best),
-                                                       __float_as_uint(st[1].best), false, false);
-            auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].second),
-                                                       __float_as_uint(st[1].second), false, false);
-            auto si = __builtin_amdgcn_permlane32_swap((unsigned)st[0].bi, (unsigned)st[1].bi,
+            auto sb = __builtin_amdgcn_permlane32_swap((unsigned)st[0].best, (unsigned)st[1].best,
                                                        false, false);
-            const float b0 = __uint_as_float(sb[0]), b1 = __uint_as_float(sb[1]);
-            const float s0 = __uint_as_float(ss[0]), s1 = __uint_as_float(ss[1]);
-            const int i0 = (int)si[0], i1 = (int)si[1];
-            const float best = fmaxf(b0, b1);
-            const float second = fmaxf(fminf(b0, b1), fmaxf(s0, s1));
-            int win = b0 > b1 ? i0 : (b1 > b0 ? i1 : min(i0, i1));
-            // uniform codebooks compare raw on-bit sums (score / v): widen eps
-            const float eps = UNI ? TIE_EPS * 4.0f : TIE_EPS;
+            auto ss = __builtin_amdgcn_permlane32_swap((unsigned)st[0].second,
+                                                       (unsigned)st[1].second, false, false);
+            auto si = __builtin_amdgcn_permlane32_swap((unsigned)st[0].tile, (unsigned)st[1].tile,
+                                                       false, false);
+            // [0] came from the lane holding codeword rows 0-3 of every group of
+            // eight (half 0), [1] from the lane holding rows 4-7
+            const int b0 = (int)sb[0], b1 = (int)sb[1];
+            const int s0 = (int)ss[0], s1 = (int)ss[1];
+            const int kbest = min(b0, b1);
+            const int ksecond = min(max(b0, b1), min(s0, s1));
+            const int slot = kbest & KEY_SLOT_MASK;
+            int win = (b1 < b0 ? (int)si[1] + 4 : (int)si[0]) + (slot & 3) + 8 * (slot >> 2);
+            const float best = __int_as_float(kbest & ~KEY_SLOT_MASK);
+            const float second = __int_as_float(ksecond & ~KEY_SLOT_MASK);
+            // TIE_EPS is in score (v * sum) units: a uniform key is key_c times
+            // that; the slot bits move a key by < 2^-19 of itself
+            const float eps = (UNI ? TIE_EPS * key_c : TIE_EPS) + second * 0x1p-18f;
 
 #ifdef MF_ABL_NOF64
-            double d2 = (double)(2.0f - best);
+            double d2 = (double)best;
 #else
             double d2 = exact_d2<MAXB>(x[o], g_mask[win], g_v64[win], B);
 #endif
             // a zero padding row can only "win" when every real sum is <= 0
             if (win >= a.N ||
-                (best - second < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN)) {
+                (second - best < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN)) {
                 // ambiguous and possibly within the threshold: exact scan,
                 // lowest index wins exact ties (the oracle's rule)
                 d2 = INFINITY;
@@ -654,7 +686,7 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
     int uniform = 1;
     double v_first = 0.0;
     for (int n = 0; n < h.Npad; ++n) {
-        hn[n] = INFINITY;           // padding rows can never win
+        hn[n] = 1.0e30f;            // padding rows (v = 0) can never win
         if (n >= N) continue;
         double v = 0.0, sq = 0.0;
         uint32_t m = 0;
@@ -669,14 +701,15 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
                                     "codeword %d is not binary-valued (entries %g and %g)", n, v, c);
                 v = c;
                 m |= 1u << b;
-                am[(size_t)n * h.KB + b] = 0x3f80;    // bf16 1.0
+                // bf16 -1.0, or -0.5 above 16 bits
+                am[(size_t)n * h.KB + b] = h.KB == 16 ? 0xbf80 : 0xbf00;
             }
             sq += c * c;
         }
         mask[n] = m;
         v64[n] = v;
-        vt[n] = (float)v;
-        hn[n] = (float)(0.5 * sq);
+        vt[n] = (float)(h.KB == 16 ? v : 2.0 * v);
+        hn[n] = (float)(0.5 + 0.5 * sq);
         if (n == 0) v_first = v;
         // uniform: every row has the same value and the same weight, so the
         // raw on-bit sum orders the codewords
@@ -684,6 +717,10 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
             uniform = 0;
     }
     h.uniform = uniform;
+    // uniform keys: t * (sqrt(weight) - sum) >= 0 for a unit trace, with a
+    // little head room for the rounding of the norm
+    h.key_c = (float)((h.KB == 16 ? 1.0 : 0.5) * std::sqrt((double)__builtin_popcount(mask[0])) *
+                      (1.0 + 0x1p-18));
     std::memcpy(blob.data(), &h, sizeof(h));
     MF_HIP_CHECK(hipMemcpy(table, blob.data(), (size_t)h.total, hipMemcpyHostToDevice));
     return uniform ? MF_CODEBOOK_UNIFORM : 0;
