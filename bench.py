@@ -156,8 +156,9 @@ def main():
     torch.cuda.synchronize(dev)
     k_ms = e0.elapsed_time(e1) / reps
     # algorithmic bytes per pixel: 2B in (u16 stack) + 2 (int16 id) + 4
-    # (magnitude) + 8 (float64 distance) + 4B (normalised traces) = 6B + 14
-    alg_bytes = px_fov * (6 * B + 14)
+    # (magnitude) + 8 (float64 distance) = 2B + 14, plus 4B of normalised
+    # traces for every decoded pixel (the FOV path keeps no others)
+    alg_bytes = px_fov * (2 * B + 14) + n_decoded * 4 * B
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     del v
 

@@ -40,6 +40,8 @@ extern "C" {
 
 #define MF_CODEBOOK_UNIFORM 1 /* flag: all codewords share weight and value   */
 
+#define MF_DECODE_TRACES_DECODED_ONLY 1 /* mf_decode_pixels flag, see there   */
+
 #define MF_DTYPE_U16     0
 #define MF_DTYPE_F32     1
 #define MF_DTYPE_F64     2
@@ -81,7 +83,14 @@ int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
  *   magnitudes f32   [Z,H,W]
  *   distances  f32 or f64 [Z,H,W] (dist_dtype), NOT masked by the thresholds
  *   traces     f32, element (z,b,y,x) at traces[z*tr_z_stride+b*tr_bit_stride
- *              + y*W + x]; may be NULL (fused path: traces not materialised)
+ *              + (y*W + x)*tr_pix_stride]; may be NULL (traces not materialised).
+ *              The reference's layout is plane-major (tr_pix_stride = 1,
+ *              tr_bit_stride = H*W); the FOV runner uses pixel-major
+ *              (tr_bit_stride = 1, tr_pix_stride = B), which mf_region_table
+ *              gathers one cache line per pixel.
+ *   flags      MF_DECODE_TRACES_DECODED_ONLY: write the traces only of pixels
+ *              whose decoded value is >= 0 (all that the region table reads);
+ *              the other entries of `traces` are left untouched.
  *
  * Blur: ksize = 2*ceil(2*sigma)+1 <= 9, BORDER_REFLECT_101, exact integer
  * arithmetic for u16.  Nearest codeword replaces sklearn NearestNeighbors
@@ -100,7 +109,7 @@ int mf_decode_pixels(const void *image, int image_dtype,
                      int16_t *decoded, float *magnitudes,
                      void *distances, int dist_dtype,
                      float *traces, int64_t tr_z_stride, int64_t tr_bit_stride,
-                     void *stream);
+                     int64_t tr_pix_stride, int flags, void *stream);
 
 /* Connected-component labelling of the decoded image: replaces the N calls to
  * skimage.measure.label(decodedImage == i) (decoding.py:165-166, 324-325,
@@ -139,7 +148,8 @@ int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
 int mf_region_table(const int16_t *decoded, const float *magnitudes,
                     const void *distances, int dist_dtype,
                     const float *traces, int64_t tr_z_stride,
-                    int64_t tr_bit_stride, const int32_t *labels,
+                    int64_t tr_bit_stride, int64_t tr_pix_stride,
+                    const int32_t *labels,
                     int B, int Z, int H, int W, int conn3d,
                     int64_t n_pixels, int64_t n_regions,
                     double *rec, float *inten, float *mean_tm, float *min_tm,

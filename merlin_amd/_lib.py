@@ -18,6 +18,7 @@ MF_DTYPE_F64 = 2
 MF_MAX_BITS = 32
 MF_MAX_RADIUS = 4
 MF_REC_COLS = 12
+MF_DECODE_TRACES_DECODED_ONLY = 1
 
 # every symbol include/merfish_hip.h declares
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
@@ -59,15 +60,15 @@ def lib():
     L.mf_decode_pixels.argtypes = [
         vp, i32, i32, i32, i32, i32, i64, i64, vp, i32, i32,
         c.POINTER(c.c_float), c.POINTER(c.c_float), f64, f64, f32,
-        vp, vp, vp, i32, vp, i64, i64, vp]
+        vp, vp, vp, i32, vp, i64, i64, i64, i32, vp]
     L.mf_label_components.restype = i32
     L.mf_label_components.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     L.mf_region_workspace_bytes.restype = i64
     L.mf_region_workspace_bytes.argtypes = [i32, i32, i32, i64, i64]
     L.mf_region_table.restype = i32
     L.mf_region_table.argtypes = [
-        vp, vp, vp, i32, vp, i64, i64, vp, i32, i32, i32, i32, i32, i64, i64,
-        vp, vp, vp, vp, vp, i64, vp]
+        vp, vp, vp, i32, vp, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64,
+        i64, vp, vp, vp, vp, vp, i64, vp]
     _lib = L
     return L
 

@@ -135,27 +135,41 @@ struct IsAssigned {
 };
 
 struct IsBoundary {
-    const uint64_t *k;
+    const uint32_t *k;
     __device__ bool operator()(int i) const { return i == 0 || k[i] != k[i - 1]; }
 };
 
-// key = ((plane-or-0) * 32768 + barcode) << root_bits | root
+// sort key of an assigned pixel: its component root (= raster index of the
+// component's first pixel)
 __global__ void __launch_bounds__(NT)
-make_keys(const int32_t *__restrict__ pix, const int16_t *__restrict__ dec,
-          const int32_t *__restrict__ L, int64_t n, int plane_px, int conn3d, int root_bits,
-          uint64_t *__restrict__ keys)
+root_keys(const int32_t *__restrict__ pix, const int32_t *__restrict__ L, int64_t n,
+          uint32_t *__restrict__ keys)
 {
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= n) return;
-    const int p = pix[i];
-    const uint64_t root = (uint64_t)L[p];
-    const uint64_t grp = conn3d ? 0u : (uint64_t)(p / plane_px);
-    keys[i] = ((grp * 32768u + (uint64_t)dec[p]) << root_bits) | root;
+    if (i < n) keys[i] = (uint32_t)L[pix[i]];
+}
+
+// Regions arrive ordered by root.  The reference emits them by z plane (2-D
+// mode), then barcode, then label order (= root order): key = plane * 32768 +
+// barcode, sorted stably.  In 2-D mode the plane is root / plane_px.
+__global__ void __launch_bounds__(NT)
+region_keys(const uint32_t *__restrict__ roots_sorted, const int32_t *__restrict__ offsets,
+            const int16_t *__restrict__ dec, int64_t n_reg, int plane_px, int conn3d,
+            uint32_t *__restrict__ keys, int32_t *__restrict__ idx)
+{
+    const int64_t j = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (j >= n_reg) return;
+    const uint32_t root = roots_sorted[offsets[j]];
+    const uint32_t grp = conn3d ? 0u : root / (uint32_t)plane_px;
+    keys[j] = grp * 32768u + (uint32_t)dec[root];
+    idx[j] = (int32_t)j;
 }
 
 struct StatsArgs {
-    const int32_t *pix;      // sorted by (group, barcode, root), raster order inside
-    const int32_t *offsets;  // [n_regions]
+    const int32_t *pix;      // sorted by root, raster order inside a region
+    const int32_t *offsets;  // [n_regions] first entry of each region, root order
+    const int32_t *order;    // [n_regions] region emitted as row r
+    int64_t tr_p;
     int64_t n_pix, n_reg;
     const int16_t *dec;
     const float *mag;
@@ -183,8 +197,9 @@ region_stats(const StatsArgs a)
     const int sub = threadIdx.x & (RSUB - 1);
     const bool valid = r < a.n_reg;
     if (!valid) r = a.n_reg - 1;          // keep all 16 lanes in the shuffles
-    const int64_t i0 = a.offsets[r];
-    const int64_t i1 = r + 1 < a.n_reg ? a.offsets[r + 1] : a.n_pix;
+    const int64_t j = a.order[r];
+    const int64_t i0 = a.offsets[j];
+    const int64_t i1 = j + 1 < a.n_reg ? a.offsets[j + 1] : a.n_pix;
     const int n = (int)(i1 - i0);
     const int plane = a.H * a.W;
     const int first = a.pix[i0];
@@ -208,7 +223,7 @@ region_stats(const StatsArgs a)
         for (int k = 0; k < RSUB; ++k) {
             const int p = __shfl(myp, k, RSUB);
             const int zz = p / plane;
-            const int64_t off = (int64_t)zz * a.tr_z + (p - zz * plane);
+            const int64_t off = (int64_t)zz * a.tr_z + (int64_t)(p - zz * plane) * a.tr_p;
             t0[k] = has0 && k < cnt ? a.traces[off + (int64_t)sub * a.tr_b] : 0.0f;
             t1[k] = has1 && k < cnt ? a.traces[off + (int64_t)(sub + RSUB) * a.tr_b] : 0.0f;
         }
@@ -291,8 +306,9 @@ region_stats(const StatsArgs a)
 
 // workspace carve-up shared by the size query and the call
 struct Plan {
-    size_t keys_a, keys_b, pix_a, pix_b, offsets, count, temp, temp_bytes, total;
-    int root_bits, key_bits;
+    size_t keys_a, keys_b, pix_a, pix_b, offsets, rkeys_a, rkeys_b, ridx_a, ridx_b, count, temp,
+        temp_bytes, total;
+    int root_bits, region_key_bits;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -303,35 +319,45 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     int rb = 1;
     while (((int64_t)1 << rb) < vol) ++rb;
     pl.root_bits = rb;
-    int gb = 15;                       // barcode < 32768
     int zb = 0;
     while ((1 << zb) < Z) ++zb;
-    pl.key_bits = rb + gb + zb;
-    if (pl.key_bits > 64) return mf::fail(MF_EUNSUPPORTED, "sort key needs %d bits", pl.key_bits);
+    pl.region_key_bits = 15 + zb;      // barcode < 32768
+    if (pl.region_key_bits > 32)
+        return mf::fail(MF_EUNSUPPORTED, "region key needs %d bits", pl.region_key_bits);
 
     const size_t np = (size_t)(n_pix > 0 ? n_pix : 1), nr = (size_t)(n_reg > 0 ? n_reg : 1);
-    size_t t1 = 0, t2 = 0, t3 = 0;
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     // size queries (null temp storage): no work is enqueued
     hipError_t e;
     e = rocprim::select(nullptr, t1, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
                         (unsigned long long *)nullptr, (size_t)vol, IsAssigned{nullptr});
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
-    e = rocprim::radix_sort_pairs(nullptr, t2, (uint64_t *)nullptr, (uint64_t *)nullptr,
+    e = rocprim::radix_sort_pairs(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (int32_t *)nullptr, (int32_t *)nullptr, np, 0u,
-                                  (unsigned)pl.key_bits);
+                                  (unsigned)pl.root_bits);
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
     e = rocprim::select(nullptr, t3, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
                         (unsigned long long *)nullptr, np, IsBoundary{nullptr});
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
-    pl.temp_bytes = t1 > t2 ? t1 : t2;
+    e = rocprim::radix_sort_pairs(nullptr, t4, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (int32_t *)nullptr, (int32_t *)nullptr, nr, 0u,
+                                  (unsigned)pl.region_key_bits);
+    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
+    pl.temp_bytes = t1;
+    if (t2 > pl.temp_bytes) pl.temp_bytes = t2;
     if (t3 > pl.temp_bytes) pl.temp_bytes = t3;
+    if (t4 > pl.temp_bytes) pl.temp_bytes = t4;
 
     size_t off = 0;
-    pl.keys_a = off; off += align_up(np * 8);
-    pl.keys_b = off; off += align_up(np * 8);
+    pl.keys_a = off; off += align_up(np * 4);
+    pl.keys_b = off; off += align_up(np * 4);
     pl.pix_a = off; off += align_up(np * 4);
     pl.pix_b = off; off += align_up(np * 4);
     pl.offsets = off; off += align_up((nr + 1) * 4);
+    pl.rkeys_a = off; off += align_up(nr * 4);
+    pl.rkeys_b = off; off += align_up(nr * 4);
+    pl.ridx_a = off; off += align_up(nr * 4);
+    pl.ridx_b = off; off += align_up(nr * 4);
     pl.count = off; off += 256;
     pl.temp = off; off += align_up(pl.temp_bytes);
     pl.total = off;
@@ -372,7 +398,8 @@ extern "C" int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixe
 extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
                                const void *distances, int dist_dtype, const float *traces,
                                int64_t tr_z_stride, int64_t tr_bit_stride,
-                               const int32_t *labels, int B, int Z, int H, int W, int conn3d,
+                               int64_t tr_pix_stride, const int32_t *labels, int B, int Z, int H,
+                               int W, int conn3d,
                                int64_t n_pixels, int64_t n_regions, double *rec, float *inten,
                                float *mean_tm, float *min_tm, void *workspace,
                                int64_t workspace_bytes, void *stream)
@@ -394,11 +421,15 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
                         (long long)pl.total);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
-    uint64_t *keys_a = reinterpret_cast<uint64_t *>(ws + pl.keys_a);
-    uint64_t *keys_b = reinterpret_cast<uint64_t *>(ws + pl.keys_b);
+    uint32_t *keys_a = reinterpret_cast<uint32_t *>(ws + pl.keys_a);
+    uint32_t *keys_b = reinterpret_cast<uint32_t *>(ws + pl.keys_b);
     int32_t *pix_a = reinterpret_cast<int32_t *>(ws + pl.pix_a);
     int32_t *pix_b = reinterpret_cast<int32_t *>(ws + pl.pix_b);
     int32_t *offsets = reinterpret_cast<int32_t *>(ws + pl.offsets);
+    uint32_t *rkeys_a = reinterpret_cast<uint32_t *>(ws + pl.rkeys_a);
+    uint32_t *rkeys_b = reinterpret_cast<uint32_t *>(ws + pl.rkeys_b);
+    int32_t *ridx_a = reinterpret_cast<int32_t *>(ws + pl.ridx_a);
+    int32_t *ridx_b = reinterpret_cast<int32_t *>(ws + pl.ridx_b);
     unsigned long long *count = reinterpret_cast<unsigned long long *>(ws + pl.count);
     void *temp = ws + pl.temp;
     size_t tb = pl.temp_bytes;
@@ -406,23 +437,34 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     // 1. assigned pixels in raster order
     MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), pix_a, count,
                                  (size_t)vol, IsAssigned{labels}, s));
-    // 2. (plane, barcode, root) keys; stable sort keeps raster order per region
-    const unsigned gp = (unsigned)((n_pixels + NT - 1) / NT);
-    hipLaunchKernelGGL(make_keys, dim3(gp), dim3(NT), 0, s, pix_a, decoded, labels, n_pixels,
-                       H * W, conn3d, pl.root_bits, keys_a);
+    // 2. group them by component root; the stable sort keeps raster order
+    //    inside a region and leaves the regions in root (= label) order
+    {
+        const unsigned gp = (unsigned)((n_pixels + NT - 1) / NT);
+        hipLaunchKernelGGL(root_keys, dim3(gp), dim3(NT), 0, s, pix_a, labels, n_pixels, keys_a);
+    }
     tb = pl.temp_bytes;
     MF_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys_a, keys_b, pix_a, pix_b,
-                                           (size_t)n_pixels, 0u, (unsigned)pl.key_bits, s));
+                                           (size_t)n_pixels, 0u, (unsigned)pl.root_bits, s));
     // 3. region starts
     tb = pl.temp_bytes;
     MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), offsets, count,
                                  (size_t)n_pixels, IsBoundary{keys_b}, s));
-    // 4. per-region rows
+    // 4. emission order of the regions: (plane, barcode), label order inside
+    {
+        const unsigned gq = (unsigned)((n_regions + NT - 1) / NT);
+        hipLaunchKernelGGL(region_keys, dim3(gq), dim3(NT), 0, s, keys_b, offsets, decoded,
+                           n_regions, H * W, conn3d, rkeys_a, ridx_a);
+    }
+    tb = pl.temp_bytes;
+    MF_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, rkeys_a, rkeys_b, ridx_a, ridx_b,
+                                           (size_t)n_regions, 0u, (unsigned)pl.region_key_bits, s));
+    // 5. per-region rows
     StatsArgs a;
-    a.pix = pix_b; a.offsets = offsets; a.n_pix = n_pixels; a.n_reg = n_regions;
+    a.pix = pix_b; a.offsets = offsets; a.order = ridx_b; a.n_pix = n_pixels; a.n_reg = n_regions;
     a.dec = decoded; a.mag = magnitudes; a.dist = distances;
     a.dist_f64 = dist_dtype == MF_DTYPE_F64;
-    a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride;
+    a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride; a.tr_p = tr_pix_stride;
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.conn3d = conn3d;
     a.rec = rec; a.inten = inten; a.mean_tm = mean_tm; a.min_tm = min_tm;
     const unsigned gr = (unsigned)((n_regions * RSUB + NT - 1) / NT);

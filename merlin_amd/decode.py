@@ -37,14 +37,18 @@ class Decode(object):
         return self._codebook
 
     def decode_fov_device(self, imageStack: torch.Tensor, scaleFactors,
-                          backgrounds) -> DecodedVolume:
+                          backgrounds, returnTraces='decoded'
+                          ) -> DecodedVolume:
         """Blur + normalise + nearest codeword for every z plane of one FOV
-        in one launch.  imageStack: uint16 [B,Z,H,W] on the GPU."""
+        in one launch.  imageStack: uint16 [B,Z,H,W] on the GPU.  By default
+        the normalised traces are kept only at decoded pixels, pixel-major
+        (all that barcode extraction reads); returnTraces=True keeps every
+        pixel's trace in the reference's layout."""
         p = self.parameters
         return self.decoder.decode_pixels_device(
             imageStack, scaleFactors, backgrounds,
             distanceThreshold=p['distance_threshold'],
-            lowPassSigma=p['lowpass_sigma'], returnTraces=True,
+            lowPassSigma=p['lowpass_sigma'], returnTraces=returnTraces,
             distanceDtype=torch.float32 if p['decode_3d'] else torch.float64)
 
     def run_fov(self, imageStack: torch.Tensor, scaleFactors, backgrounds,

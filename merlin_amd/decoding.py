@@ -47,7 +47,10 @@ class DecodedVolume(object):
     """Device-resident output of one decode call: Z planes of one FOV.
 
     decoded int16 [Z,H,W], magnitudes f32 [Z,H,W], distances f32|f64 [Z,H,W],
-    traces f32 [Z,B,H,W] (or None when not materialised)."""
+    traces f32 [Z,B,H,W] (or None when not materialised).  ``traces`` may be a
+    strided view: the FOV runner stores it pixel-major ([Z,H,W,B] in memory)
+    and only at decoded pixels (``traces_decoded_only``); the entries of
+    undecoded pixels are then undefined."""
 
     def __init__(self, decoded, magnitudes, distances, traces, bit_count):
         self.decoded = decoded
@@ -55,6 +58,7 @@ class DecodedVolume(object):
         self.distances = distances
         self.traces = traces
         self.bit_count = bit_count
+        self.traces_decoded_only = False
         self._tables = {}
 
     @property
@@ -167,7 +171,7 @@ class PixelBasedDecoder(object):
                              distanceThreshold: float = 0.5176,
                              magnitudeThreshold: float = 1,
                              lowPassSigma: float = 1,
-                             returnTraces: bool = True,
+                             returnTraces=True,
                              distanceDtype=torch.float64) -> DecodedVolume:
         """decode_pixels on a device-resident stack.
 
@@ -207,13 +211,23 @@ class PixelBasedDecoder(object):
             decoded = torch.empty((Z, H, W), dtype=torch.int16, device=dev)
             mags = torch.empty((Z, H, W), dtype=torch.float32, device=dev)
             dist = torch.empty((Z, H, W), dtype=distanceDtype, device=dev)
-            traces = torch.empty((Z, B, H, W), dtype=torch.float32,
-                                 device=dev) if returnTraces else None
+            flags = 0
+            if returnTraces == 'decoded':
+                store = torch.empty((Z, H, W, B), dtype=torch.float32,
+                                    device=dev)
+                traces = store.permute(0, 3, 1, 2)
+                flags = _lib.MF_DECODE_TRACES_DECODED_ONLY
+            elif returnTraces:
+                traces = torch.empty((Z, B, H, W), dtype=torch.float32,
+                                     device=dev)
+            else:
+                traces = None
             ddt = _lib.MF_DTYPE_F64 if distanceDtype == torch.float64 \
                 else _lib.MF_DTYPE_F32
             cb = self._codebook_device()
             import ctypes
             fp = ctypes.POINTER(ctypes.c_float)
+            has = traces is not None
             _lib.check(L.mf_decode_pixels(
                 imageData.data_ptr(), dt, B, Z, H, W,
                 imageData.stride(0), imageData.stride(1),
@@ -222,11 +236,14 @@ class PixelBasedDecoder(object):
                 float(lowPassSigma), float(distanceThreshold),
                 float(np.float32(magnitudeThreshold)),
                 decoded.data_ptr(), mags.data_ptr(), dist.data_ptr(), ddt,
-                _ptr(traces), B * H * W if returnTraces else 0,
-                H * W if returnTraces else 0, _stream_ptr(dev)))
+                _ptr(traces), traces.stride(0) if has else 0,
+                traces.stride(1) if has else 0,
+                traces.stride(3) if has else 1, flags, _stream_ptr(dev)))
         # keep the input alive until the stream has consumed it
         imageData.record_stream(torch.cuda.current_stream(dev))
-        return DecodedVolume(decoded, mags, dist, traces, B)
+        vol = DecodedVolume(decoded, mags, dist, traces, B)
+        vol.traces_decoded_only = bool(flags)
+        return vol
 
     def decode_pixels(self, imageData: np.ndarray,
                       scaleFactors: np.ndarray = None,
@@ -351,7 +368,8 @@ class PixelBasedDecoder(object):
                 _lib.check(L.mf_region_table(
                     vol.decoded.data_ptr(), vol.magnitudes.data_ptr(),
                     dist.data_ptr(), ddt, tr.data_ptr(), tr.stride(0),
-                    tr.stride(1), labels.data_ptr(), B, Z, H, W, int(is3D),
+                    tr.stride(1), tr.stride(3), labels.data_ptr(), B, Z, H, W,
+                    int(is3D),
                     n_pix, n_reg, rec.data_ptr(), inten.data_ptr(),
                     _ptr(mean_tm), _ptr(min_tm), ws.data_ptr(), ws_bytes, sp))
             table = RegionTable(rec, inten, mean_tm, min_tm)

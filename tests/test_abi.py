@@ -42,7 +42,7 @@ def test_argument_errors_are_reported():
     # null pointers are rejected before any GPU work
     rc = L.mf_decode_pixels(None, 0, 16, 1, 8, 8, 64, 64, None, 1, 0, None, None,
                             1.0, 0.5, 1.0, None, None, None, 1, None, 0, 0,
-                            None)
+                            1, 0, None)
     assert rc == -1
     rc = L.mf_label_components(None, 1, 8, 8, 0, None, None, None)
     assert rc == -1

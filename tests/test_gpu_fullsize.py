@@ -25,8 +25,12 @@ def fov(gpu_device):
     bg = rng.uniform(0, 5, 16)
     task = Decode(ArrayCodebook(cb), {'crop_width': 100}, device=gpu_device)
     bc, vol = task.run_fov(img, sf, bg, fov=3)
+    # run_fov keeps the traces of decoded pixels only (pixel-major); a second
+    # launch with the reference's full plane-major traces
+    full = task.decode_fov_device(img, sf, bg, returnTraces=True)
     torch.cuda.synchronize()
-    return dict(cb=cb, img=img, sf=sf, bg=bg, task=task, bc=bc, vol=vol)
+    return dict(cb=cb, img=img, sf=sf, bg=bg, task=task, bc=bc, vol=vol,
+                full=full)
 
 
 def test_crops_match_oracle(fov):
@@ -50,8 +54,13 @@ def test_crops_match_oracle(fov):
         gs = (z, slice(y0 + ya, y0 + yb), slice(x0 + xa, x0 + xb))
         assert np.array_equal(vol.decoded[gs].cpu().numpy(), di[sl])
         assert np.array_equal(vol.magnitudes[gs].cpu().numpy(), pm[sl])
+        want = npt[(slice(None),) + sl]
         assert np.array_equal(
-            vol.traces[z, :, gs[1], gs[2]].cpu().numpy(), npt[(slice(None),) + sl])
+            fov['full'].traces[z, :, gs[1], gs[2]].cpu().numpy(), want)
+        hit = di[sl] >= 0
+        assert vol.traces_decoded_only and hit.any()
+        assert np.array_equal(
+            vol.traces[z, :, gs[1], gs[2]].cpu().numpy()[:, hit], want[:, hit])
         got = vol.distances[gs].cpu().numpy()
         clear = (gap[sl] > 1e-4) | (di[sl] >= 0)
         assert np.array_equal(got[clear], d[sl][clear])
@@ -68,7 +77,10 @@ def test_planes_are_independent(fov):
         assert torch.equal(one.decoded[0], fov['vol'].decoded[z])
         assert torch.equal(one.magnitudes[0], fov['vol'].magnitudes[z])
         assert torch.equal(one.distances[0], fov['vol'].distances[z])
-        assert torch.equal(one.traces[0], fov['vol'].traces[z])
+        assert torch.equal(one.traces[0], fov['full'].traces[z])
+        assert torch.equal(one.decoded[0], fov['full'].decoded[z])
+        hit = one.decoded[0] >= 0
+        assert torch.equal(one.traces[0][:, hit], fov['vol'].traces[z][:, hit])
 
 
 def test_component_and_record_invariants(fov):
