@@ -37,6 +37,7 @@ extern "C" {
 #define MF_MAX_BITS     32   /* bits per codeword supported by the kernels  */
 #define MF_MAX_RADIUS    4   /* blur radius: ksize <= 9, i.e. sigma <= 2    */
 #define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
+#define MF_FRAME_COLS   10   /* float64 columns of mf_region_frame          */
 
 #define MF_CODEBOOK_UNIFORM 1 /* flag: all codewords share weight and value   */
 
@@ -139,7 +140,9 @@ int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
  *            2 area        3 mean_intensity      4 max_intensity
  *            5 mean_distance  6 min_distance
  *            7 centroid z  8 centroid row (y)    9 centroid column (x)
- *            10 first-pixel linear index         11 reserved (0)
+ *            10 first-pixel linear index
+ *            11 position of the row inside its (z plane, barcode) group: the
+ *               DataFrame index the reference assigns (decoding.py:246-252)
  *   inten    f32 [n_regions, B]  per-bit mean of the normalised traces
  *   mean_tm  f32 [n_regions, B]  per-bit mean of trace*magnitude, or NULL
  *   min_tm   f32 [n_regions, B]  per-bit min  of trace*magnitude, or NULL
@@ -153,6 +156,28 @@ int mf_region_table(const int16_t *decoded, const float *magnitudes,
                     int B, int Z, int H, int W, int conn3d,
                     int64_t n_pixels, int64_t n_regions,
                     double *rec, float *inten, float *mean_tm, float *min_tm,
+                    void *workspace, int64_t workspace_bytes, void *stream);
+
+/* Crop / area filter and column gather of the region table: the tail of
+ * extract_barcodes_with_index (decoding.py:222-252) for every row at once.
+ * A row is kept iff  crop_width < x < crop_shape0 - crop_width  and
+ * crop_width < y < crop_shape1 - crop_width  (the reference compares x with
+ * shape[0] and y with shape[1]) and area >= minimum_area.  Kept rows keep their
+ * order.
+ *
+ *   out64  f64 [MF_FRAME_COLS][n_regions] column-major, first *count entries of
+ *          each column valid: barcode_id, mean_intensity, max_intensity, area,
+ *          mean_distance, min_distance, x, y, z, index-in-group
+ *   out32  f32 [B][n_regions]: the per-bit intensities, same convention
+ *   count  int64 [1]: number of kept rows
+ * out64 / out32 / count may be device memory or page-locked host memory that
+ * is mapped into the device (hipHostMalloc): the kernels then write the rows
+ * straight across PCIe.  Read them after the stream has been synchronised. */
+int64_t mf_region_frame_workspace_bytes(int64_t n_regions);
+int mf_region_frame(const double *rec, const float *inten, int64_t n_regions,
+                    int B, int conn3d, double crop_width, double crop_shape0,
+                    double crop_shape1, double minimum_area,
+                    double *out64, float *out32, int64_t *count,
                     void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

@@ -18,13 +18,15 @@ MF_DTYPE_F64 = 2
 MF_MAX_BITS = 32
 MF_MAX_RADIUS = 4
 MF_REC_COLS = 12
+MF_FRAME_COLS = 10
 MF_DECODE_TRACES_DECODED_ONLY = 1
 
 # every symbol include/merfish_hip.h declares
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
            'mf_codebook_table_bytes', 'mf_codebook_prepare',
            'mf_decode_pixels', 'mf_label_components',
-           'mf_region_workspace_bytes', 'mf_region_table')
+           'mf_region_workspace_bytes', 'mf_region_table',
+           'mf_region_frame_workspace_bytes', 'mf_region_frame')
 
 _lib = None
 
@@ -69,6 +71,11 @@ def lib():
     L.mf_region_table.argtypes = [
         vp, vp, vp, i32, vp, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64,
         i64, vp, vp, vp, vp, vp, i64, vp]
+    L.mf_region_frame_workspace_bytes.restype = i64
+    L.mf_region_frame_workspace_bytes.argtypes = [i64]
+    L.mf_region_frame.restype = i32
+    L.mf_region_frame.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64, f64,
+                                  vp, vp, vp, vp, i64, vp]
     _lib = L
     return L
 

@@ -102,15 +102,38 @@ ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int Z, int H, int W, int 
 __global__ void __launch_bounds__(NT)
 ccl_flatten(int32_t *L, int n, unsigned long long *counts)
 {
-    // grid-stride: each thread keeps private counts, one atomic pair per wave
-    // at the very end (a same-address atomic per 64 pixels serialises)
+    // grid-stride over groups of four labels; each thread keeps private counts
+    // and the block issues ONE atomic pair at the very end (same-address
+    // atomics serialise at ~17 ns each, so their number is what matters)
+    __shared__ int s_fg[NT / 64], s_roots[NT / 64];
     int fg = 0, roots = 0;
-    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const int n4 = n >> 2;
+    int4 *L4 = reinterpret_cast<int4 *>(L);
+    for (int q = blockIdx.x * NT + threadIdx.x; q < n4; q += gridDim.x * NT) {
+        int4 v = L4[q];
+        if ((v.x & v.y & v.z & v.w) < 0) continue;      // four unassigned pixels
+        int *e = reinterpret_cast<int *>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = e[k];
+            if (p >= 0) {
+                int r = p;
+                int t = L[r];
+                while (t != r) { r = t; t = L[r]; }
+                e[k] = r;
+                ++fg;
+                roots += r == 4 * q + k;
+            }
+        }
+        L4[q] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // tail
+        const int i = (n4 << 2) + threadIdx.x;
         const int p = L[i];
         if (p >= 0) {
             int r = p;
-            int q = L[r];
-            while (q != r) { r = q; q = L[r]; }
+            int t = L[r];
+            while (t != r) { r = t; t = L[r]; }
             L[i] = r;
             ++fg;
             roots += r == i;
@@ -121,7 +144,12 @@ ccl_flatten(int32_t *L, int n, unsigned long long *counts)
         fg += __shfl_down(fg, off);
         roots += __shfl_down(roots, off);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { s_fg[threadIdx.x >> 6] = fg; s_roots[threadIdx.x >> 6] = roots; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fg = roots = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { fg += s_fg[w]; roots += s_roots[w]; }
         if (fg) atomicAdd(counts + 0, (unsigned long long)fg);
         if (roots) atomicAdd(counts + 1, (unsigned long long)roots);
     }
@@ -169,6 +197,7 @@ struct StatsArgs {
     const int32_t *pix;      // sorted by root, raster order inside a region
     const int32_t *offsets;  // [n_regions] first entry of each region, root order
     const int32_t *order;    // [n_regions] region emitted as row r
+    const uint32_t *rkeys;   // [n_regions] sorted (plane, barcode) keys of the rows
     int64_t tr_p;
     int64_t n_pix, n_reg;
     const int16_t *dec;
@@ -182,27 +211,47 @@ struct StatsArgs {
     float *inten, *mean_tm, *min_tm;
 };
 
-// 16 lanes per region.  The region's pixels are fetched 16 at a time, one per
-// lane (independent, mostly coalesced loads), and handed round with width-16
-// shuffles, so the float sums still run in the reference's sequential raster
-// order but the memory latency is paid once per 16 pixels instead of once per
-// pixel.  Lane `sub` owns bits sub, sub+16; the scalar statistics are computed
-// redundantly by the 16 lanes and written by lane 0.
+// 16 lanes per region.  The region's pixels are taken 16 at a time: every lane
+// fetches one pixel's index, magnitude and distance, works out where its trace
+// lives and parks that in LDS; then all 16 lanes walk the 16 staged pixels in
+// raster order (broadcast LDS reads), lane `sub` accumulating bits sub and
+// sub+16, so the float sums run in the reference's sequential order while the
+// memory latency and the index arithmetic are paid once per 16 pixels.  The
+// scalar statistics are computed redundantly by the 16 lanes and written by
+// lane 0.
 constexpr int RSUB = 16;
+
+struct StagePix {          // 32 bytes
+    int64_t toff;          // element offset of the pixel's trace (bit 0)
+    double d;              // distance            | pass 2: weight m / sum(m)
+    float m;               // magnitude
+    int z, y, x;           // pass 2: coordinates
+};
+
+__device__ __forceinline__ void group_sync()
+{
+    // the 16 lanes of a group sit in one wave: order the LDS traffic only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __global__ void __launch_bounds__(NT)
 region_stats(const StatsArgs a)
 {
+    __shared__ StagePix stage[NT / RSUB][RSUB];
     int64_t r = ((int64_t)blockIdx.x * NT + threadIdx.x) / RSUB;
     const int sub = threadIdx.x & (RSUB - 1);
+    StagePix *st = stage[threadIdx.x / RSUB];
     const bool valid = r < a.n_reg;
-    if (!valid) r = a.n_reg - 1;          // keep all 16 lanes in the shuffles
+    if (!valid) r = a.n_reg - 1;          // keep whole groups alive
     const int64_t j = a.order[r];
     const int64_t i0 = a.offsets[j];
     const int64_t i1 = j + 1 < a.n_reg ? a.offsets[j + 1] : a.n_pix;
     const int n = (int)(i1 - i0);
     const int plane = a.H * a.W;
     const int first = a.pix[i0];
+    const int zfirst = first / plane;
     const bool want_tm = a.mean_tm || a.min_tm;
 
     // pass 1: magnitude sum / max, distance sum / min; per-bit sums
@@ -211,27 +260,39 @@ region_stats(const StatsArgs a)
     float s0 = 0.0f, stm0 = 0.0f, mn0 = INFINITY;     // bit sub
     float s1 = 0.0f, stm1 = 0.0f, mn1 = INFINITY;     // bit sub + 16
     const bool has0 = sub < a.B, has1 = sub + RSUB < a.B;
+    const int64_t boff0 = (int64_t)sub * a.tr_b, boff1 = (int64_t)(sub + RSUB) * a.tr_b;
+    int myp = first;
+    float mym = 0.0f;
     for (int64_t base = i0; base < i1; base += RSUB) {
         const int cnt = (int)min((int64_t)RSUB, i1 - base);
-        const int myp = sub < cnt ? a.pix[base + sub] : first;
-        const float mym = a.mag[myp];
-        const double myd = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[myp]
-                                      : (double)reinterpret_cast<const float *>(a.dist)[myp];
+        if (sub < cnt) {
+            myp = a.pix[base + sub];
+            mym = a.mag[myp];
+            const double myd = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[myp]
+                                          : (double)reinterpret_cast<const float *>(a.dist)[myp];
+            // a 2-D region lies in one plane; only 3-D needs the division
+            const int zz = a.conn3d ? myp / plane : zfirst;
+            StagePix sp;
+            sp.toff = (int64_t)zz * a.tr_z + (int64_t)(myp - zz * plane) * a.tr_p;
+            sp.d = myd;
+            sp.m = mym;
+            sp.z = sp.y = sp.x = 0;
+            st[sub] = sp;
+        }
+        group_sync();
         // issue this lane's trace loads for the whole chunk first
         float t0[RSUB], t1[RSUB];
 #pragma unroll
         for (int k = 0; k < RSUB; ++k) {
-            const int p = __shfl(myp, k, RSUB);
-            const int zz = p / plane;
-            const int64_t off = (int64_t)zz * a.tr_z + (int64_t)(p - zz * plane) * a.tr_p;
-            t0[k] = has0 && k < cnt ? a.traces[off + (int64_t)sub * a.tr_b] : 0.0f;
-            t1[k] = has1 && k < cnt ? a.traces[off + (int64_t)(sub + RSUB) * a.tr_b] : 0.0f;
+            const int64_t off = st[k < cnt ? k : 0].toff;
+            t0[k] = has0 && k < cnt ? a.traces[off + boff0] : 0.0f;
+            t1[k] = has1 && k < cnt ? a.traces[off + boff1] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < RSUB; ++k) {
-            const float m = __shfl(mym, k, RSUB);
-            const double d = __shfl(myd, k, RSUB);
             if (k < cnt) {
+                const float m = st[k].m;
+                const double d = st[k].d;
                 msum += (double)m;
                 mmax = fmaxf(mmax, m);
                 dsum += d;
@@ -245,40 +306,63 @@ region_stats(const StatsArgs a)
                 }
             }
         }
+        group_sync();      // the next chunk (or pass 2) overwrites the stage
     }
     // pass 2: magnitude-weighted centroid
     double cz, cy, cx;
     if (n == 1) {
-        cz = first / plane; cy = (first % plane) / a.W; cx = first % a.W;
+        cz = zfirst; cy = (first % plane) / a.W; cx = first % a.W;
     } else {
         cz = cy = cx = 0.0;
         for (int64_t base = i0; base < i1; base += RSUB) {
             const int cnt = (int)min((int64_t)RSUB, i1 - base);
-            const int myp = sub < cnt ? a.pix[base + sub] : first;
-            const float mym = a.mag[myp];
+            if (sub < cnt) {
+                if (n > RSUB) {            // else still in registers from pass 1
+                    myp = a.pix[base + sub];
+                    mym = a.mag[myp];
+                }
+                const int zz = a.conn3d ? myp / plane : zfirst;
+                const int rem = myp - zz * plane;
+                StagePix sp;
+                sp.toff = 0;
+                sp.d = (double)mym / msum;
+                sp.m = mym;
+                sp.z = zz;
+                sp.y = rem / a.W;
+                sp.x = rem - sp.y * a.W;
+                st[sub] = sp;
+            }
+            group_sync();
 #pragma unroll
             for (int k = 0; k < RSUB; ++k) {
-                const int p = __shfl(myp, k, RSUB);
-                const float m = __shfl(mym, k, RSUB);
                 if (k < cnt) {
-                    const double w = (double)m / msum;
-                    cz += (double)(p / plane) * w;
-                    cy += (double)((p % plane) / a.W) * w;
-                    cx += (double)(p % a.W) * w;
+                    const double w = st[k].d;
+                    cz += (double)st[k].z * w;
+                    cy += (double)st[k].y * w;
+                    cx += (double)st[k].x * w;
                 }
             }
+            group_sync();
         }
     }
     if (!valid) return;
     double mean_int = msum / n, mean_d = n > 1 ? dsum / n : dsum;
     if (a.conn3d) mean_int = (double)(float)mean_int;        // regionprops: f32
     if (a.conn3d && !a.dist_f64) mean_d = (double)(float)mean_d;
-    if (!a.conn3d) cz = first / plane;
+    if (!a.conn3d) cz = zfirst;
 
     if (sub == 0) {
+        // position inside the (plane, barcode) group: rows are sorted by that
+        // key, so it is r minus the first row carrying the key
+        const uint32_t key = a.rkeys[r];
+        int64_t lo = 0, hi = r;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.rkeys[mid] < key) lo = mid + 1; else hi = mid;
+        }
         double *row = a.rec + r * MF_REC_COLS;
         row[0] = (double)a.dec[first];
-        row[1] = (double)(first / plane);
+        row[1] = (double)zfirst;
         row[2] = (double)n;
         row[3] = mean_int;
         row[4] = (double)mmax;
@@ -288,7 +372,7 @@ region_stats(const StatsArgs a)
         row[8] = cy;
         row[9] = cx;
         row[10] = (double)first;
-        row[11] = 0.0;
+        row[11] = (double)(r - lo);
     }
     // per-bit means: sequential float32 sums in raster order, then / n
     // (np.mean(list of f32 rows, axis 0), decoding.py:197, 220, 330)
@@ -303,6 +387,11 @@ region_stats(const StatsArgs a)
         if (a.min_tm) a.min_tm[r * a.B + sub + RSUB] = mn1;
     }
 }
+
+// ~2e5 regions with <= 18 key bits: three onesweep passes beat rocPRIM's
+// default choice for this size (a block sort plus ~18 merge launches)
+using RegionSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                    rocprim::default_config, 4096>;
 
 // workspace carve-up shared by the size query and the call
 struct Plan {
@@ -339,9 +428,10 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     e = rocprim::select(nullptr, t3, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
                         (unsigned long long *)nullptr, np, IsBoundary{nullptr});
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
-    e = rocprim::radix_sort_pairs(nullptr, t4, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                  (int32_t *)nullptr, (int32_t *)nullptr, nr, 0u,
-                                  (unsigned)pl.region_key_bits);
+    e = rocprim::radix_sort_pairs<RegionSortConfig>(nullptr, t4, (uint32_t *)nullptr,
+                                                    (uint32_t *)nullptr, (int32_t *)nullptr,
+                                                    (int32_t *)nullptr, nr, 0u,
+                                                    (unsigned)pl.region_key_bits);
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
     pl.temp_bytes = t1;
     if (t2 > pl.temp_bytes) pl.temp_bytes = t2;
@@ -364,7 +454,110 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     return MF_OK;
 }
 
+// ------------------------------------------------------------ frame rows ---
+
+struct KeepRow {
+    const double *rec;
+    double lo, x_hi, y_hi, min_area;
+    __device__ bool operator()(int r) const
+    {
+        const double *row = rec + (int64_t)r * MF_REC_COLS;
+        const double x = row[9], y = row[8];
+        return x > lo && x < x_hi && y > lo && y < y_hi && row[2] >= min_area;
+    }
+};
+
+// column-major gather of the kept rows; `count` was written by the select
+__global__ void __launch_bounds__(NT)
+frame_gather(const double *__restrict__ rec, const float *__restrict__ inten,
+             const int32_t *__restrict__ sel, const unsigned long long *__restrict__ count,
+             int64_t n_reg, int B, int zcol, double *__restrict__ out64,
+             float *__restrict__ out32)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= (int64_t)*count) return;
+    const int64_t r = sel[i];
+    const double *row = rec + r * MF_REC_COLS;
+    const int cols[MF_FRAME_COLS] = {0, 3, 4, 2, 5, 6, 9, 8, zcol, 11};
+#pragma unroll
+    for (int c = 0; c < MF_FRAME_COLS; ++c) out64[(int64_t)c * n_reg + i] = row[cols[c]];
+    for (int b = 0; b < B; ++b) out32[(int64_t)b * n_reg + i] = inten[r * B + b];
+}
+
+// device-side address of a buffer the kernels may write: device memory or
+// page-locked host memory that is mapped into the device's address space
+template <typename T>
+int device_view(T *p, T **out, const char *what)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess || !at.devicePointer) {
+        (void)hipGetLastError();
+        return mf::fail(MF_EINVAL, "%s is neither device memory nor mapped pinned host memory", what);
+    }
+    *out = reinterpret_cast<T *>(at.devicePointer);
+    return MF_OK;
+}
+
 }  // namespace
+
+extern "C" int64_t mf_region_frame_workspace_bytes(int64_t n_regions)
+{
+    if (n_regions < 0 || n_regions > INT32_MAX) return mf::fail(MF_EINVAL, "bad region count");
+    const size_t nr = (size_t)(n_regions > 0 ? n_regions : 1);
+    size_t t = 0;
+    const hipError_t e =
+        rocprim::select(nullptr, t, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
+                        (unsigned long long *)nullptr, nr, KeepRow{nullptr, 0, 0, 0, 0});
+    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
+    return (int64_t)(align_up(nr * 4) + 256 + align_up(t));
+}
+
+extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_regions, int B,
+                               int conn3d, double crop_width, double crop_shape0,
+                               double crop_shape1, double minimum_area, double *out64,
+                               float *out32, int64_t *count, void *workspace,
+                               int64_t workspace_bytes, void *stream)
+{
+    if (!count) return mf::fail(MF_EINVAL, "null pointer argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int64_t *d_count = nullptr;
+    int rc = device_view(count, &d_count, "count");
+    if (rc) return rc;
+    if (n_regions == 0) {
+        MF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+        return MF_OK;
+    }
+    if (!rec || !inten || !out64 || !out32 || !workspace)
+        return mf::fail(MF_EINVAL, "null pointer argument");
+    if (n_regions < 0 || n_regions > INT32_MAX || B < 1)
+        return mf::fail(MF_EINVAL, "bad sizes");
+    const int64_t need = mf_region_frame_workspace_bytes(n_regions);
+    if (need < 0) return (int)need;
+    if (workspace_bytes < need)
+        return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes", (long long)workspace_bytes,
+                        (long long)need);
+    double *d64 = nullptr;
+    float *d32 = nullptr;
+    if ((rc = device_view(out64, &d64, "out64")) || (rc = device_view(out32, &d32, "out32")))
+        return rc;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    int32_t *sel = reinterpret_cast<int32_t *>(ws);
+    void *temp = ws + align_up((size_t)n_regions * 4) + 256;
+    size_t tb = (size_t)need - align_up((size_t)n_regions * 4) - 256;
+    // exclusive crop on the centroid with the reference's quirk: x is compared
+    // with shape[0] and y with shape[1] (decoding.py:244)
+    const KeepRow keep{rec, crop_width, crop_shape0 - crop_width, crop_shape1 - crop_width,
+                       minimum_area};
+    MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), sel,
+                                 reinterpret_cast<unsigned long long *>(d_count),
+                                 (size_t)n_regions, keep, s));
+    const unsigned g = (unsigned)((n_regions + NT - 1) / NT);
+    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(NT), 0, s, rec, inten, sel,
+                       reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
+                       conn3d ? 7 : 1, d64, d32);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
 
 extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, int conn3d,
                                    int32_t *labels, int64_t *counts, void *stream)
@@ -373,6 +566,8 @@ extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, 
     if (Z < 1 || H < 1 || W < 1) return mf::fail(MF_EINVAL, "bad shape Z=%d H=%d W=%d", Z, H, W);
     const int64_t vol = (int64_t)Z * H * W;
     if (vol > INT32_MAX) return mf::fail(MF_EUNSUPPORTED, "volume exceeds 2^31 pixels");
+    if (reinterpret_cast<uintptr_t>(labels) & 15)
+        return mf::fail(MF_EINVAL, "labels must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n = (int)vol;
     const unsigned grid = (unsigned)((n + NT - 1) / NT);
@@ -457,11 +652,12 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
                            n_regions, H * W, conn3d, rkeys_a, ridx_a);
     }
     tb = pl.temp_bytes;
-    MF_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, rkeys_a, rkeys_b, ridx_a, ridx_b,
-                                           (size_t)n_regions, 0u, (unsigned)pl.region_key_bits, s));
+    MF_HIP_CHECK(rocprim::radix_sort_pairs<RegionSortConfig>(
+        temp, tb, rkeys_a, rkeys_b, ridx_a, ridx_b, (size_t)n_regions, 0u,
+        (unsigned)pl.region_key_bits, s));
     // 5. per-region rows
     StatsArgs a;
-    a.pix = pix_b; a.offsets = offsets; a.order = ridx_b; a.n_pix = n_pixels; a.n_reg = n_regions;
+    a.pix = pix_b; a.offsets = offsets; a.order = ridx_b; a.rkeys = rkeys_b; a.n_pix = n_pixels; a.n_reg = n_regions;
     a.dec = decoded; a.mag = magnitudes; a.dist = distances;
     a.dist_f64 = dist_dtype == MF_DTYPE_F64;
     a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride; a.tr_p = tr_pix_stride;

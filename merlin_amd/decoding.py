@@ -453,42 +453,34 @@ class PixelBasedDecoder(object):
                          cropWidth, globalAligner, minimumArea, cropShape
                          ) -> pandas.DataFrame:
         """_frame_from_rows for every row of a device-resident table: the crop
-        / area filter and the column gather run on the GPU, so only the kept
-        rows cross PCIe, already column-major.  globalAligner is applied to
-        the kept rows (it is a per-row affine map, globalalign.py:141-148)."""
+        / area filter and the column gather run on the GPU (mf_region_frame),
+        which writes only the kept rows, column-major, into page-locked
+        buffers the DataFrame then owns.  globalAligner is applied to the
+        kept rows (it is a per-row affine map, globalalign.py:141-148)."""
         intensityColumns = ['intensity_{}'.format(i) for i in range(bitCount)]
         rec = table.rec_d
         n = rec.shape[0]
         if n == 0:
             return pandas.DataFrame(columns=COLUMN_NAMES + intensityColumns)
         dev = rec.device
+        L = _lib.lib()
+        h64 = self._pinned((_lib.MF_FRAME_COLS, n), torch.float64)
+        h32 = self._pinned((bitCount, n), torch.float32)
+        hcount = self._pinned((1,), torch.int64)
         with torch.cuda.device(dev):
-            x, y, area = rec[:, 9], rec[:, 8], rec[:, 2]
-            keep = ((x > cropWidth) & (x < cropShape[0] - cropWidth)
-                    & (y > cropWidth) & (y < cropShape[1] - cropWidth)
-                    & (area >= minimumArea))
-            gkey = rec[:, 0] if is3D else rec[:, 1] * 65536.0 + rec[:, 0]
-            ar = torch.arange(n, device=dev)
-            first = torch.ones(n, dtype=torch.bool, device=dev)
-            first[1:] = gkey[1:] != gkey[:-1]
-            # start row of each (plane, barcode) group, spread to its rows
-            start = torch.nonzero(first).squeeze(1)[
-                torch.cumsum(first.to(torch.int32), 0) - 1]
-            sel = torch.nonzero(keep).squeeze(1)
-            zcol = 7 if is3D else 1
-            out64 = torch.stack([
-                rec[sel, 0], rec[sel, 3], rec[sel, 4], rec[sel, 2],
-                rec[sel, 5], rec[sel, 6], rec[sel, 9], rec[sel, 8],
-                rec[sel, zcol], (ar - start)[sel].to(torch.float64)])
-            out32 = table.inten_d[sel].t().contiguous()
-            m = out64.shape[1]
-            h64 = self._pinned(out64.shape, torch.float64)
-            h32 = self._pinned(out32.shape, torch.float32)
-            h64.copy_(out64, non_blocking=True)
-            h32.copy_(out32, non_blocking=True)
+            ws_bytes = _lib.check(L.mf_region_frame_workspace_bytes(n))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            # the kernels write the kept rows straight into the pinned buffers
+            _lib.check(L.mf_region_frame(
+                rec.data_ptr(), table.inten_d.data_ptr(), n, bitCount,
+                int(is3D), float(cropWidth), float(cropShape[0]),
+                float(cropShape[1]), float(minimumArea), h64.data_ptr(),
+                h32.data_ptr(), hcount.data_ptr(), ws.data_ptr(), ws_bytes,
+                _stream_ptr(dev)))
             torch.cuda.current_stream(dev).synchronize()
-        a64 = h64.numpy()
-        a32 = h32.numpy()
+        m = int(hcount[0])
+        a64 = h64.numpy()[:, :m]
+        a32 = h32.numpy()[:, :m]
         xs, ys, zs = a64[6], a64[7], a64[8]
         if globalAligner is not None:
             centroids = np.stack([zs, xs, ys], axis=1)
