@@ -108,8 +108,15 @@ def main():
     sf = initial_scale_factors(fovs[0])
     bg = np.zeros(B)
 
-    def step(i):
-        bc, vol = task.run_fov(fovs[i % 2], sf, bg, fov=i)
+    def run(count):
+        # a step = one FOV through Decode.run_fovs (stack in HBM -> barcode
+        # DataFrame on the host); run_fovs overlaps FOV k's PCIe/host tail
+        # with FOV k+1's kernels, and every FOV's DataFrame is complete
+        # before the loop ends
+        bc = vol = None
+        stacks = (fovs[i % 2] for i in range(count))
+        for bc, vol in task.run_fovs(stacks, sf, bg):
+            pass
         return bc, vol
 
     def barrier():
@@ -118,16 +125,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        bc, vol = step(i)
+    if os.environ.get('BENCH_SERIAL'):       # one run_fov call per step
+        def run(count):                      # noqa: F811
+            bc = vol = None
+            for i in range(count):
+                bc, vol = task.run_fov(fovs[i % 2], sf, bg, fov=i)
+            return bc, vol
+
+    if args.warmup:
+        run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ts = time.perf_counter()
-        bc, vol = step(i)
-        if os.environ.get('BENCH_DEBUG'):
-            torch.cuda.synchronize(dev)
-            print('step', i, (time.perf_counter() - ts) * 1e3, file=sys.stderr)
+    bc, vol = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:

@@ -51,6 +51,32 @@ class Decode(object):
             lowPassSigma=p['lowpass_sigma'], returnTraces=returnTraces,
             distanceDtype=torch.float32 if p['decode_3d'] else torch.float64)
 
+    def _finish_fov(self, pending, vol, fov, globalAligner, zPositions):
+        p = self.parameters
+        bc = self.decoder._frame_finish(pending, vol.bit_count, fov,
+                                        globalAligner)
+        if p['remove_z_duplicated_barcodes']:
+            from merlin_amd import barcodefilters
+            zpos = zPositions if zPositions is not None \
+                else list(range(vol.shape[0]))
+            bc = barcodefilters.remove_zplane_duplicates_all_barcodeids(
+                bc, p['z_duplicate_zPlane_threshold'],
+                p['z_duplicate_xy_pixel_threshold'], zpos)
+        return bc
+
+    def _enqueue_fov(self, imageStack, scaleFactors, backgrounds, side=None):
+        """Queue decode + labelling + region table + frame rows of one FOV.
+        Blocks once, on the pixel / region counts that size the tables."""
+        p = self.parameters
+        is3D = bool(p['decode_3d'])
+        vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
+        table = self.decoder.region_table(vol, is3D)
+        Z, H, W = vol.shape
+        pending = self.decoder._frame_enqueue(
+            table, is3D, vol.bit_count, self.cropWidth, p['minimum_area'],
+            (Z, H, W) if is3D else (H, W), stream=side)
+        return vol, pending
+
     def run_fov(self, imageStack: torch.Tensor, scaleFactors, backgrounds,
                 fov: int, globalAligner=None, zPositions=None):
         """decode.py:92-175 for one FOV.  Returns (barcodes DataFrame,
@@ -60,16 +86,30 @@ class Decode(object):
         2-D mode labels every plane in one pass and emits the rows in the
         order the reference writes them (plane, barcode index, label order);
         decode_3d labels the volume with 26-connectivity."""
-        p = self.parameters
-        vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
-        bc = self.decoder.extract_barcodes(
-            vol, fov, self.cropWidth, None, globalAligner, p['minimum_area'],
-            is3D=bool(p['decode_3d']))
-        if p['remove_z_duplicated_barcodes']:
-            from merlin_amd import barcodefilters
-            zpos = zPositions if zPositions is not None \
-                else list(range(vol.shape[0]))
-            bc = barcodefilters.remove_zplane_duplicates_all_barcodeids(
-                bc, p['z_duplicate_zPlane_threshold'],
-                p['z_duplicate_xy_pixel_threshold'], zpos)
-        return bc, vol
+        vol, pending = self._enqueue_fov(imageStack, scaleFactors, backgrounds)
+        return self._finish_fov(pending, vol, fov, globalAligner,
+                                zPositions), vol
+
+    def run_fovs(self, imageStacks, scaleFactors, backgrounds, fovs=None,
+                 globalAligner=None, zPositions=None):
+        """run_fov over a sequence of FOVs (the loop the reference spreads
+        over fragment processes, decode.py:68-75), yielding (barcodes,
+        DecodedVolume) per FOV in order.  The frame rows of FOV k cross PCIe
+        on a side stream and its DataFrame is assembled on the host while the
+        GPU already decodes FOV k+1."""
+        dev = self.decoder._dev()
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream(dev)
+        prev = None
+        for k, stack in enumerate(imageStacks):
+            fov = k if fovs is None else fovs[k]
+            vol, pending = self._enqueue_fov(stack, scaleFactors, backgrounds,
+                                             side)
+            if prev is not None:
+                pv, pp, pf = prev
+                yield self._finish_fov(pp, pv, pf, globalAligner,
+                                       zPositions), pv
+            prev = (vol, pending, fov)
+        if prev is not None:
+            pv, pp, pf = prev
+            yield self._finish_fov(pp, pv, pf, globalAligner, zPositions), pv

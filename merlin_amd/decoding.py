@@ -449,35 +449,54 @@ class PixelBasedDecoder(object):
         second copy."""
         return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
 
-    def _frame_on_device(self, table: RegionTable, is3D, bitCount, fov,
-                         cropWidth, globalAligner, minimumArea, cropShape
-                         ) -> pandas.DataFrame:
-        """_frame_from_rows for every row of a device-resident table: the crop
-        / area filter and the column gather run on the GPU (mf_region_frame),
-        which writes only the kept rows, column-major, into page-locked
-        buffers the DataFrame then owns.  globalAligner is applied to the
-        kept rows (it is a per-row affine map, globalalign.py:141-148)."""
-        intensityColumns = ['intensity_{}'.format(i) for i in range(bitCount)]
+    def _frame_enqueue(self, table: RegionTable, is3D, bitCount, cropWidth,
+                       minimumArea, cropShape, stream=None):
+        """Launch mf_region_frame for every row of a device-resident table:
+        the crop / area filter and the column gather run on the GPU, which
+        writes only the kept rows, column-major, into page-locked buffers.
+        Returns the pending state for _frame_finish.  With ``stream`` the work
+        runs on that side stream (after what the current stream has queued),
+        so it overlaps whatever the caller launches next."""
         rec = table.rec_d
         n = rec.shape[0]
         if n == 0:
-            return pandas.DataFrame(columns=COLUMN_NAMES + intensityColumns)
+            return None
         dev = rec.device
         L = _lib.lib()
         h64 = self._pinned((_lib.MF_FRAME_COLS, n), torch.float64)
         h32 = self._pinned((bitCount, n), torch.float32)
         hcount = self._pinned((1,), torch.int64)
         with torch.cuda.device(dev):
-            ws_bytes = _lib.check(L.mf_region_frame_workspace_bytes(n))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            # the kernels write the kept rows straight into the pinned buffers
-            _lib.check(L.mf_region_frame(
-                rec.data_ptr(), table.inten_d.data_ptr(), n, bitCount,
-                int(is3D), float(cropWidth), float(cropShape[0]),
-                float(cropShape[1]), float(minimumArea), h64.data_ptr(),
-                h32.data_ptr(), hcount.data_ptr(), ws.data_ptr(), ws_bytes,
-                _stream_ptr(dev)))
-            torch.cuda.current_stream(dev).synchronize()
+            cur = torch.cuda.current_stream(dev)
+            run = cur if stream is None else stream
+            if run is not cur:
+                run.wait_stream(cur)
+            with torch.cuda.stream(run):
+                ws_bytes = _lib.check(L.mf_region_frame_workspace_bytes(n))
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                # the kernels write the kept rows straight into the pinned
+                # buffers
+                _lib.check(L.mf_region_frame(
+                    rec.data_ptr(), table.inten_d.data_ptr(), n, bitCount,
+                    int(is3D), float(cropWidth), float(cropShape[0]),
+                    float(cropShape[1]), float(minimumArea), h64.data_ptr(),
+                    h32.data_ptr(), hcount.data_ptr(), ws.data_ptr(),
+                    ws_bytes, run.cuda_stream))
+                done = torch.cuda.Event()
+                done.record(run)
+        # `table` and `ws` stay referenced until the event has fired
+        return (table, ws, h64, h32, hcount, done)
+
+    def _frame_finish(self, pending, bitCount, fov, globalAligner
+                      ) -> pandas.DataFrame:
+        """Wait for _frame_enqueue's rows and hand them to pandas without a
+        copy.  globalAligner is applied to the kept rows (it is a per-row
+        affine map, globalalign.py:141-148)."""
+        intensityColumns = ['intensity_{}'.format(i) for i in range(bitCount)]
+        if pending is None:
+            return pandas.DataFrame(columns=COLUMN_NAMES + intensityColumns)
+        _, _, h64, h32, hcount, done = pending
+        done.synchronize()
         m = int(hcount[0])
         a64 = h64.numpy()[:, :m]
         a32 = h32.numpy()[:, :m]
@@ -502,6 +521,14 @@ class PixelBasedDecoder(object):
             cols[c] = a32[i]
         return pandas.DataFrame(cols, index=a64[9].astype(np.int64),
                                 copy=False)
+
+    def _frame_on_device(self, table: RegionTable, is3D, bitCount, fov,
+                         cropWidth, globalAligner, minimumArea, cropShape
+                         ) -> pandas.DataFrame:
+        """_frame_from_rows for every row of a device-resident table."""
+        pending = self._frame_enqueue(table, is3D, bitCount, cropWidth,
+                                      minimumArea, cropShape)
+        return self._frame_finish(pending, bitCount, fov, globalAligner)
 
     def extract_barcodes_with_index(
             self, barcodeIndex: int, decodedImage: np.ndarray,

@@ -96,6 +96,39 @@ def test_run_fov_matches_drop_in_api(gpu_device):
     assert np.array_equal(bc.index.to_numpy(), exp.index.to_numpy())
 
 
+def test_run_fovs_pipeline_equals_run_fov(gpu_device):
+    """The pipelined FOV loop (frame rows of FOV k cross PCIe on a side stream
+    while FOV k+1 decodes) yields exactly run_fov's tables, in order,
+    including an FOV with no barcode at all and z-duplicate removal."""
+    import torch
+    from merlin_amd.decode import Decode
+    cb = load_golden('g2_synth192')['codebook']
+    stacks = [synth_stack(cb, (3, 96, 128), 70, seed=30 + k) for k in range(4)]
+    stacks[2] = np.zeros_like(stacks[2])            # nothing decodes
+    dev_stacks = [torch.from_numpy(s).to(gpu_device) for s in stacks]
+    sf = np.full(16, 380.0)
+    bg = np.zeros(16)
+    tform = np.float32([[0.1, 0, 7.0], [0, 0.1, -3.0], [0, 0, 1]])
+    for extra in ({}, {'remove_z_duplicated_barcodes': True}):
+        params = dict({'crop_width': 5, 'minimum_area': 1}, **extra)
+        task = Decode(ArrayCodebook(cb), params, device=gpu_device)
+        fovs = [11, 12, 13, 14]
+        got = list(task.run_fovs(iter(dev_stacks), sf, bg, fovs=fovs,
+                                 globalAligner=AffineAligner(tform)))
+        assert len(got) == 4
+        for k, (bc, vol) in enumerate(got):
+            ebc, evol = task.run_fov(dev_stacks[k], sf, bg, fovs[k],
+                                     globalAligner=AffineAligner(tform))
+            assert torch.equal(vol.decoded, evol.decoded)
+            assert list(bc.columns) == list(ebc.columns)
+            assert np.array_equal(frame_to_array(bc, 16),
+                                  frame_to_array(ebc, 16))
+            assert np.array_equal(bc.index.to_numpy(), ebc.index.to_numpy())
+            assert (len(bc) == 0) == (k == 2)
+            if len(bc):
+                assert (bc['fov'] == fovs[k]).all()
+
+
 def test_optimize_iterations_match_oracle(gpu_device):
     """Two chained OptimizeIteration passes over the reference test-suite FOVs
     (test_analysis_parameters.json:17-41: fov_per_iteration 2) against the
