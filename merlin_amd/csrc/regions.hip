@@ -54,36 +54,50 @@ __device__ __forceinline__ void unite(int32_t *L, int a, int b)
     }
 }
 
+// ccl_init / ccl_merge run on a (ceil(W/256), H, Z) grid: x, y, z come from
+// the block indices, no integer division per pixel.
+//
+// Initial labels: every pixel of a horizontal run (same barcode, same row,
+// inside one 64-pixel wave segment) points at the run's first pixel, found
+// with a ballot -- the intra-row links cost no atomics at all.
 __global__ void __launch_bounds__(NT)
-ccl_init(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int n)
+ccl_init(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int H, int W)
 {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i < n) L[i] = dec[i] >= 0 ? i : -1;
+    const int x = blockIdx.x * NT + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = ((int)blockIdx.z * H + (int)blockIdx.y) * W + x;
+    const int code = x < W ? (int)dec[i] : -1;
+    const int prev = __shfl_up(code, 1);
+    const bool cont = code >= 0 && lane > 0 && prev == code;
+    const unsigned long long breaks = __ballot(!cont);          // bit 0 is always set
+    const unsigned long long upto = breaks & (~0ull >> (63 - lane));
+    const int start = 63 - __clzll((long long)upto);
+    if (x < W) L[i] = code >= 0 ? i - (lane - start) : -1;
 }
 
 __global__ void __launch_bounds__(NT)
-ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int Z, int H, int W, int conn3d)
+ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int H, int W, int conn3d)
 {
-    const int total = Z * H * W;
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= total) return;
+    const int x = blockIdx.x * NT + threadIdx.x;
+    if (x >= W) return;
+    const int y = blockIdx.y, z = blockIdx.z;
+    const int i = (z * H + y) * W + x;
     const int16_t code = dec[i];
     if (code < 0) return;
-    const int x = i % W;
-    const int y = (i / W) % H;
-    const int z = i / (W * H);
-    // same plane, backward neighbours W, NW, N, NE.  If N matches, W / NW /
-    // NE are 8-adjacent to N and get united with it by their own threads, so
-    // one union suffices; likewise W is adjacent to NW.
+    // Same plane, backward neighbours W, NW, N, NE.  Runs are already linked,
+    // so a union is needed only where a run first touches a run of the row
+    // above: with N, unless W and NW match (then the W pixel made that link);
+    // without N, with NW unless W matches, and with NE.  A run cut by the
+    // 64-pixel segment boundary is re-joined at its lane 0.
     const bool w = x > 0 && dec[i - 1] == code;
     const bool n = y > 0 && dec[i - W] == code;
     const bool nw = y > 0 && x > 0 && dec[i - W - 1] == code;
     const bool ne = y > 0 && x + 1 < W && dec[i - W + 1] == code;
+    if (w && (threadIdx.x & 63) == 0) unite(L, i, i - 1);
     if (n) {
-        unite(L, i, i - W);
+        if (!(w && nw)) unite(L, i, i - W);
     } else {
-        if (nw) unite(L, i, i - W - 1);
-        else if (w) unite(L, i, i - 1);
+        if (nw && !w) unite(L, i, i - W - 1);
         if (ne) unite(L, i, i - W + 1);
     }
     if (conn3d && z > 0) {
@@ -571,9 +585,11 @@ extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int n = (int)vol;
     const unsigned grid = (unsigned)((n + NT - 1) / NT);
+    if (H > 65535 || Z > 65535) return mf::fail(MF_EUNSUPPORTED, "H and Z must be <= 65535");
     MF_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), s));
-    hipLaunchKernelGGL(ccl_init, dim3(grid), dim3(NT), 0, s, decoded, labels, n);
-    hipLaunchKernelGGL(ccl_merge, dim3(grid), dim3(NT), 0, s, decoded, labels, Z, H, W, conn3d);
+    const dim3 g3((unsigned)((W + NT - 1) / NT), (unsigned)H, (unsigned)Z);
+    hipLaunchKernelGGL(ccl_init, g3, dim3(NT), 0, s, decoded, labels, H, W);
+    hipLaunchKernelGGL(ccl_merge, g3, dim3(NT), 0, s, decoded, labels, H, W, conn3d);
     const unsigned fgrid = grid < 2048u ? grid : 2048u;
     hipLaunchKernelGGL(ccl_flatten, dim3(fgrid), dim3(NT), 0, s, labels, n,
                        reinterpret_cast<unsigned long long *>(counts));
