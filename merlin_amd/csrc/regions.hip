@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -481,21 +482,31 @@ struct KeepRow {
     }
 };
 
-// column-major gather of the kept rows; `count` was written by the select
-__global__ void __launch_bounds__(NT)
+// column-major gather of the kept rows; `count` was written by the select.
+// The stores cross PCIe when the outputs are pinned host memory, so a wave
+// lives long, and every CU it sits on loses a workgroup slot of the decode
+// kernel running beside it on another stream (that kernel needs all 512
+// VGPRs of a SIMD for its two waves).  Hence few, large workgroups: four
+// 1024-thread groups saturate the link and touch only four CUs (measured per
+// 7-z FOV: 1 WG 4.64 ms, 2: 3.56, 4: 3.35, 8: 3.49, 16: 3.63; 48x256: 3.64).
+constexpr int GATHER_NT = 1024;
+
+__global__ void __launch_bounds__(GATHER_NT)
 frame_gather(const double *__restrict__ rec, const float *__restrict__ inten,
              const int32_t *__restrict__ sel, const unsigned long long *__restrict__ count,
              int64_t n_reg, int B, int zcol, double *__restrict__ out64,
              float *__restrict__ out32)
 {
-    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= (int64_t)*count) return;
-    const int64_t r = sel[i];
-    const double *row = rec + r * MF_REC_COLS;
+    const int64_t m = (int64_t)*count;
     const int cols[MF_FRAME_COLS] = {0, 3, 4, 2, 5, 6, 9, 8, zcol, 11};
+    for (int64_t i = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x; i < m;
+         i += (int64_t)gridDim.x * GATHER_NT) {
+        const int64_t r = sel[i];
+        const double *row = rec + r * MF_REC_COLS;
 #pragma unroll
-    for (int c = 0; c < MF_FRAME_COLS; ++c) out64[(int64_t)c * n_reg + i] = row[cols[c]];
-    for (int b = 0; b < B; ++b) out32[(int64_t)b * n_reg + i] = inten[r * B + b];
+        for (int c = 0; c < MF_FRAME_COLS; ++c) out64[(int64_t)c * n_reg + i] = row[cols[c]];
+        for (int b = 0; b < B; ++b) out32[(int64_t)b * n_reg + i] = inten[r * B + b];
+    }
 }
 
 // device-side address of a buffer the kernels may write: device memory or
@@ -565,8 +576,10 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
     MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), sel,
                                  reinterpret_cast<unsigned long long *>(d_count),
                                  (size_t)n_regions, keep, s));
-    const unsigned g = (unsigned)((n_regions + NT - 1) / NT);
-    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(NT), 0, s, rec, inten, sel,
+    unsigned g = (unsigned)((n_regions + GATHER_NT - 1) / GATHER_NT);
+    if (g > 4u) g = 4u;
+    if (const char *e = std::getenv("MF_GATHER_WGS")) g = (unsigned)std::atoi(e);   // tuning aid
+    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel,
                        reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
                        conn3d ? 7 : 1, d64, d32);
     MF_HIP_CHECK(hipGetLastError());

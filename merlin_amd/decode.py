@@ -36,6 +36,17 @@ class Decode(object):
     def get_codebook(self):
         return self._codebook
 
+    def _side_stream(self, dev):
+        """Stream for mf_region_frame's PCIe-bound gather, created once.
+        (A CU-masked stream was measured too: slower than an ordinary one.)"""
+        import os
+        if os.environ.get('MF_NO_SIDE'):           # tuning aid: no overlap
+            return None
+        if getattr(self, '_side', None) is None:
+            with torch.cuda.device(dev):
+                self._side = torch.cuda.Stream(dev)
+        return self._side
+
     def decode_fov_device(self, imageStack: torch.Tensor, scaleFactors,
                           backgrounds, returnTraces='decoded'
                           ) -> DecodedVolume:
@@ -64,18 +75,22 @@ class Decode(object):
                 p['z_duplicate_xy_pixel_threshold'], zpos)
         return bc
 
-    def _enqueue_fov(self, imageStack, scaleFactors, backgrounds, side=None):
-        """Queue decode + labelling + region table + frame rows of one FOV.
-        Blocks once, on the pixel / region counts that size the tables."""
+    def _enqueue_decode(self, imageStack, scaleFactors, backgrounds):
+        """Stage 1 of a FOV: decode kernel + labelling, nothing blocks."""
+        vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
+        lab = self.decoder._label_enqueue(vol, bool(self.parameters['decode_3d']))
+        return vol, lab
+
+    def _enqueue_table(self, vol, lab, side=None):
+        """Stage 2: region table + frame rows.  Blocks once, on the pixel /
+        region counts that size the tables."""
         p = self.parameters
         is3D = bool(p['decode_3d'])
-        vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
-        table = self.decoder.region_table(vol, is3D)
+        table = self.decoder.region_table(vol, is3D, pendingLabels=lab)
         Z, H, W = vol.shape
-        pending = self.decoder._frame_enqueue(
+        return self.decoder._frame_enqueue(
             table, is3D, vol.bit_count, self.cropWidth, p['minimum_area'],
             (Z, H, W) if is3D else (H, W), stream=side)
-        return vol, pending
 
     def run_fov(self, imageStack: torch.Tensor, scaleFactors, backgrounds,
                 fov: int, globalAligner=None, zPositions=None):
@@ -86,7 +101,8 @@ class Decode(object):
         2-D mode labels every plane in one pass and emits the rows in the
         order the reference writes them (plane, barcode index, label order);
         decode_3d labels the volume with 26-connectivity."""
-        vol, pending = self._enqueue_fov(imageStack, scaleFactors, backgrounds)
+        vol, lab = self._enqueue_decode(imageStack, scaleFactors, backgrounds)
+        pending = self._enqueue_table(vol, lab)
         return self._finish_fov(pending, vol, fov, globalAligner,
                                 zPositions), vol
 
@@ -94,22 +110,36 @@ class Decode(object):
                  globalAligner=None, zPositions=None):
         """run_fov over a sequence of FOVs (the loop the reference spreads
         over fragment processes, decode.py:68-75), yielding (barcodes,
-        DecodedVolume) per FOV in order.  The frame rows of FOV k cross PCIe
-        on a side stream and its DataFrame is assembled on the host while the
-        GPU already decodes FOV k+1."""
+        DecodedVolume) per FOV in order.
+
+        Software pipeline, three FOVs in flight: the decode kernel and the
+        labelling of FOV k+1 are queued before the host waits for FOV k's
+        region counts, so that wait costs the GPU nothing; FOV k's frame rows
+        cross PCIe on a side stream and FOV k-1's DataFrame is assembled on
+        the host meanwhile."""
         dev = self.decoder._dev()
-        with torch.cuda.device(dev):
-            side = torch.cuda.Stream(dev)
-        prev = None
+        side = self._side_stream(dev)
+        decoded = None      # (vol, labels pending, fov): stage 1 queued
+        tabled = None       # (vol, frame pending, fov): stage 2 queued
+
+        def finish(t):
+            return self._finish_fov(t[1], t[0], t[2], globalAligner,
+                                    zPositions), t[0]
+
         for k, stack in enumerate(imageStacks):
             fov = k if fovs is None else fovs[k]
-            vol, pending = self._enqueue_fov(stack, scaleFactors, backgrounds,
-                                             side)
-            if prev is not None:
-                pv, pp, pf = prev
-                yield self._finish_fov(pp, pv, pf, globalAligner,
-                                       zPositions), pv
-            prev = (vol, pending, fov)
-        if prev is not None:
-            pv, pp, pf = prev
-            yield self._finish_fov(pp, pv, pf, globalAligner, zPositions), pv
+            nxt = self._enqueue_decode(stack, scaleFactors, backgrounds) \
+                + (fov,)
+            if decoded is not None:
+                pending = self._enqueue_table(decoded[0], decoded[1], side)
+                if tabled is not None:
+                    yield finish(tabled)
+                tabled = (decoded[0], pending, decoded[2])
+            decoded = nxt
+        if decoded is not None:
+            pending = self._enqueue_table(decoded[0], decoded[1], side)
+            if tabled is not None:
+                yield finish(tabled)
+            tabled = (decoded[0], pending, decoded[2])
+        if tabled is not None:
+            yield finish(tabled)

@@ -323,30 +323,39 @@ class PixelBasedDecoder(object):
 
     # --------------------------------------------------------- region table --
 
-    def region_table(self, vol: DecodedVolume, is3D: bool = False,
-                     withRefactorStats: bool = False) -> RegionTable:
-        """CCL + region aggregation of every barcode at once on the GPU
-        (replaces the per-index label/regionprops loop, decoding.py:165-221,
-        323-334, 359-369).  Cached on the DecodedVolume."""
-        key = (bool(is3D), bool(withRefactorStats))
-        if key in vol._tables:
-            return vol._tables[key]
-        if (bool(is3D), True) in vol._tables:
-            return vol._tables[(bool(is3D), True)]
-        if vol.traces is None:
-            raise ValueError('region extraction needs the pixel traces')
+    def _label_enqueue(self, vol: DecodedVolume, is3D: bool):
+        """Queue the connected-component labelling of a volume and the copy of
+        its (pixel, region) counts to the host; returns the pending state for
+        _table_enqueue.  Does not block."""
         L = _lib.lib()
         dev = vol.decoded.device
         Z, H, W = vol.shape
-        B = vol.bit_count
         with torch.cuda.device(dev):
             sp = _stream_ptr(dev)
             labels = torch.empty((Z, H, W), dtype=torch.int32, device=dev)
-            counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            counts = torch.empty(2, dtype=torch.int64, device=dev)
             _lib.check(L.mf_label_components(
                 vol.decoded.data_ptr(), Z, H, W, int(is3D),
                 labels.data_ptr(), counts.data_ptr(), sp))
-            n_pix, n_reg = (int(v) for v in counts.cpu())
+            hcounts = self._pinned((2,), torch.int64)
+            hcounts.copy_(counts, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        return (labels, counts, hcounts, done)
+
+    def _table_enqueue(self, vol: DecodedVolume, pending, is3D: bool,
+                       withRefactorStats: bool) -> RegionTable:
+        """Wait for the counts of _label_enqueue (the one host sync of a FOV),
+        size the tables and queue mf_region_table."""
+        L = _lib.lib()
+        labels, _, hcounts, done = pending
+        dev = vol.decoded.device
+        Z, H, W = vol.shape
+        B = vol.bit_count
+        done.synchronize()
+        n_pix, n_reg = int(hcounts[0]), int(hcounts[1])
+        with torch.cuda.device(dev):
+            sp = _stream_ptr(dev)
             rec = torch.empty((n_reg, _lib.MF_REC_COLS), dtype=torch.float64,
                               device=dev)
             inten = torch.empty((n_reg, B), dtype=torch.float32, device=dev)
@@ -372,9 +381,27 @@ class PixelBasedDecoder(object):
                     int(is3D),
                     n_pix, n_reg, rec.data_ptr(), inten.data_ptr(),
                     _ptr(mean_tm), _ptr(min_tm), ws.data_ptr(), ws_bytes, sp))
-            table = RegionTable(rec, inten, mean_tm, min_tm)
+        return RegionTable(rec, inten, mean_tm, min_tm)
+
+    def region_table(self, vol: DecodedVolume, is3D: bool = False,
+                     withRefactorStats: bool = False,
+                     pendingLabels=None) -> RegionTable:
+        """CCL + region aggregation of every barcode at once on the GPU
+        (replaces the per-index label/regionprops loop, decoding.py:165-221,
+        323-334, 359-369).  Cached on the DecodedVolume."""
+        key = (bool(is3D), bool(withRefactorStats))
+        if key in vol._tables:
+            return vol._tables[key]
+        if (bool(is3D), True) in vol._tables:
+            return vol._tables[(bool(is3D), True)]
+        if vol.traces is None:
+            raise ValueError('region extraction needs the pixel traces')
+        if pendingLabels is None:
+            pendingLabels = self._label_enqueue(vol, is3D)
+        table = self._table_enqueue(vol, pendingLabels, is3D,
+                                    withRefactorStats)
         vol._tables[key] = table
-        vol.labels = labels
+        vol.labels = pendingLabels[0]
         return table
 
     # ------------------------------------------ extract_barcodes_with_index --
