@@ -1,5 +1,7 @@
-"""Time the decode kernel alone for the library named by MERFISH_HIP_LIB."""
-import os, sys, time
+"""Time the decode kernel alone for the library named by MERFISH_HIP_LIB:
+the FOV-path configuration (traces at decoded pixels only) and the plain one,
+min / median of 6 blocks of 10 launches after 20 warm-up launches."""
+import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -11,12 +13,22 @@ task = Decode(cb, {'crop_width': 100}, device=dev)
 img = synthetic_fov(cb.get_barcodes(), 7, 2048, 2048, 40000, 1234, dev)
 sf = bench.initial_scale_factors(img); bg = np.zeros(16)
 rng = np.random.default_rng(0)
-for name, s in (('equal_sf', sf), ('random_sf', sf * rng.uniform(0.9, 1.1, 16))):
-    for tr in (True, False):
-        f = lambda: task.decoder.decode_pixels_device(img, s, bg, 0.5167, 1, 1, tr, torch.float64)
-        f(); torch.cuda.synchronize()
+cfgs = [('equal_sf', sf, 'decoded'), ('random_sf', sf * rng.uniform(0.9, 1.1, 16), 'decoded'),
+        ('equal_sf', sf, False)]
+fs = [(n, tr, (lambda s=s, tr=tr: task.decoder.decode_pixels_device(img, s, bg, 0.5167, 1, 1, tr, torch.float64)))
+      for n, s, tr in cfgs]
+for _ in range(7):
+    for _, _, f in fs: f()
+torch.cuda.synchronize()
+res = {i: [] for i in range(len(fs))}
+for blk in range(6):
+    for i, (_, _, f) in enumerate(fs):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): v = f()
+        for _ in range(10): v = f()
         e1.record(); torch.cuda.synchronize()
-        print(os.environ.get('MERFISH_HIP_LIB', 'default'), name, 'traces' if tr else 'notraces', '%.3f ms' % (e0.elapsed_time(e1)/5), 'decoded', int((v.decoded >= 0).sum()))
+        res[i].append(e0.elapsed_time(e1) / 10)
+name = os.path.basename(os.environ.get('MERFISH_HIP_LIB', 'default'))
+for i, (n, tr, _) in enumerate(fs):
+    r = sorted(res[i])
+    print('%-18s %-9s traces=%-7s min %.3f med %.3f ms' % (name, n, tr, r[0], r[len(r) // 2]))

@@ -61,7 +61,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the start of the blob, 256-byte aligned; a function of N and B only).
 struct CbHeader {
     int32_t magic, N, B, Npad, KB, uniform;
-    float key_c, pad1;
+    float key_c, key_scale;
     int64_t off_a, off_mask, off_v, off_hn, off_v64, off_cb64, total;
 };
 constexpr int32_t CB_MAGIC = 0x4d464342;   // "MFCB"
@@ -102,32 +102,40 @@ __device__ __forceinline__ int reflect101(int i, int n)
 template <typename PIX> struct HType { using type = uint32_t; };
 template <> struct HType<float> { using type = float; };
 
-// Running two smallest codeword keys of one pixel.  A key is half the squared
-// distance to the codeword up to a per-codebook positive factor (see the tile
-// loop), so it is >= 0 and its float bits order like a signed integer; the low
-// 4 bits carry the accumulator slot it came from (a relative perturbation of
-// < 2^-19, i.e. the key keeps its *relative* precision where it matters, at
-// small distances) and the 32-codeword tile is recorded whenever the smallest
-// key changes.  Two keys per step: min3 / med3 / min.
+// Running two smallest codeword keys of one pixel.  A key is a float that
+// grows with the distance to the codeword (see the tile loop); its low 4
+// mantissa bits carry the accumulator slot it came from (a relative
+// perturbation of < 2^-19) and the 32-codeword tile is recorded whenever the
+// smallest key changes.  Keys of either sign are compared as floats; four keys
+// per step: 2 x (min3, med3) + min3.
 struct Top2 {
-    int best, second, tile;
+    float best, second;
+    int tile;
 };
 constexpr int KEY_SLOT_MASK = 15;
-constexpr int KEY_INIT = 0x7f7fffff;     // FLT_MAX
+constexpr float KEY_INIT = 3.0e38f;
 
-__device__ __forceinline__ int score_key(float s, int slot)
+__device__ __forceinline__ float score_key(float s, int slot)
 {
-    return (__float_as_int(s) & ~KEY_SLOT_MASK) | slot;
+    return __int_as_float((__float_as_int(s) & ~KEY_SLOT_MASK) | slot);
 }
 
-__device__ __forceinline__ void top2_update2(Top2 &t, int k1, int k2)
+// v_min3_f32 without the canonicalisation the compiler puts in front of fminf
+// (keys are never NaN)
+__device__ __forceinline__ float fmin3(float a, float b, float c)
 {
-    // v_med3_f32 orders non-negative floats like the integers (a key that
-    // rounding made slightly negative is the winner either way)
-    const int m = __float_as_int(__builtin_amdgcn_fmed3f(
-        __int_as_float(t.best), __int_as_float(k1), __int_as_float(k2)));
-    t.best = min(min(t.best, k1), k2);
-    t.second = min(t.second, m);
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ void top2_update4(Top2 &t, float k1, float k2, float k3, float k4)
+{
+    const float m1 = __builtin_amdgcn_fmed3f(t.best, k1, k2);
+    const float b1 = fmin3(t.best, k1, k2);
+    const float m2 = __builtin_amdgcn_fmed3f(b1, k3, k4);
+    t.best = fmin3(b1, k3, k4);
+    t.second = fmin3(t.second, m1, m2);
 }
 
 // Correctly rounded n / d from the correctly rounded reciprocal r = RN(1/d):
@@ -205,7 +213,7 @@ decode_kernel(const DecodeArgs a)
     const PIX *img = reinterpret_cast<const PIX *>(a.img);
     const uint32_t *g_mask = reinterpret_cast<const uint32_t *>(a.cbt + a.off_mask);
     const double *g_v64 = reinterpret_cast<const double *>(a.cbt + a.off_v64);
-    const float key_c = reinterpret_cast<const CbHeader *>(a.cbt)->key_c;
+    const float key_scale = reinterpret_cast<const CbHeader *>(a.cbt)->key_scale;
 
     auto load_chunk = [&](int c0, int cn) {   // cn multiple of 32
         const u32x4 *src = reinterpret_cast<const u32x4 *>(a.cbt + a.off_a + (size_t)c0 * MAXB * 2);
@@ -466,11 +474,11 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         // the table entries are -t (t = 1, or 1/2 above 16 bits),
-                        // so acc = start - t * (sum of the on bits).  Uniform
-                        // codebooks start at key_c >= t * sqrt(weight) >= t * sum:
-                        // the accumulator is the key, key = d^2 / (2 v / t)
+                        // so acc = -t * (sum of the on bits).  For a uniform
+                        // codebook that is the key: d^2 / 2 = 1 + acc * v / t for a
+                        // unit trace.  (The zero start is an MFMA inline constant.)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[tt][i] = UNI ? key_c : 0.0f;
+                        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.0f;
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -488,7 +496,7 @@ decode_kernel(const DecodeArgs a)
                     // padding rows of a uniform table are caught after the merge.
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
-                        const int before = st[tt].best;
+                        const float before = st[tt].best;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
                             float s4[4];
@@ -505,9 +513,8 @@ decode_kernel(const DecodeArgs a)
                                 s4[2] = fmaf(vv.z, acc[tt][4 * gq + 2], hh.z);
                                 s4[3] = fmaf(vv.w, acc[tt][4 * gq + 3], hh.w);
                             }
-                            top2_update2(st[tt], score_key(s4[0], 4 * gq + 0),
-                                         score_key(s4[1], 4 * gq + 1));
-                            top2_update2(st[tt], score_key(s4[2], 4 * gq + 2),
+                            top2_update4(st[tt], score_key(s4[0], 4 * gq + 0),
+                                         score_key(s4[1], 4 * gq + 1), score_key(s4[2], 4 * gq + 2),
                                          score_key(s4[3], 4 * gq + 3));
                         }
                         st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
@@ -517,25 +524,26 @@ decode_kernel(const DecodeArgs a)
 
             // ---- merge lane halves, exact float64 distance, thresholds ----
             // after the swaps both states in a lane belong to its own pixel
-            auto sb = __builtin_amdgcn_permlane32_swap((unsigned)st[0].best, (unsigned)st[1].best,
-                                                       false, false);
-            auto ss = __builtin_amdgcn_permlane32_swap((unsigned)st[0].second,
-                                                       (unsigned)st[1].second, false, false);
+            auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].best),
+                                                       __float_as_uint(st[1].best), false, false);
+            auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].second),
+                                                       __float_as_uint(st[1].second), false, false);
             auto si = __builtin_amdgcn_permlane32_swap((unsigned)st[0].tile, (unsigned)st[1].tile,
                                                        false, false);
             // [0] came from the lane holding codeword rows 0-3 of every group of
             // eight (half 0), [1] from the lane holding rows 4-7
-            const int b0 = (int)sb[0], b1 = (int)sb[1];
-            const int s0 = (int)ss[0], s1 = (int)ss[1];
-            const int kbest = min(b0, b1);
-            const int ksecond = min(max(b0, b1), min(s0, s1));
-            const int slot = kbest & KEY_SLOT_MASK;
-            int win = (b1 < b0 ? (int)si[1] + 4 : (int)si[0]) + (slot & 3) + 8 * (slot >> 2);
-            const float best = __int_as_float(kbest & ~KEY_SLOT_MASK);
-            const float second = __int_as_float(ksecond & ~KEY_SLOT_MASK);
-            // TIE_EPS is in score (v * sum) units: a uniform key is key_c times
+            const float b0 = __uint_as_float(sb[0]), b1 = __uint_as_float(sb[1]);
+            const float s0 = __uint_as_float(ss[0]), s1 = __uint_as_float(ss[1]);
+            const bool from1 = b1 < b0;
+            const float kbest = from1 ? b1 : b0;
+            const float ksecond = fmin3(from1 ? b0 : b1, s0, s1);
+            const int slot = __float_as_int(kbest) & KEY_SLOT_MASK;
+            int win = (from1 ? (int)si[1] + 4 : (int)si[0]) + (slot & 3) + 8 * (slot >> 2);
+            const float best = __int_as_float(__float_as_int(kbest) & ~KEY_SLOT_MASK);
+            const float second = __int_as_float(__float_as_int(ksecond) & ~KEY_SLOT_MASK);
+            // TIE_EPS is in score (v * sum) units: a uniform key is t / v times
             // that; the slot bits move a key by < 2^-19 of itself
-            const float eps = (UNI ? TIE_EPS * key_c : TIE_EPS) + second * 0x1p-18f;
+            const float eps = (UNI ? TIE_EPS * key_scale : TIE_EPS) + fabsf(second) * 0x1p-18f;
 
 #ifdef MF_ABL_NOF64
             double d2 = (double)best;
@@ -543,8 +551,12 @@ decode_kernel(const DecodeArgs a)
             double d2 = exact_d2<MAXB>(x[o], g_mask[win], g_v64[win], B);
 #endif
             // a zero padding row can only "win" when every real sum is <= 0
+#ifdef MF_ABL_NOSCAN
+            if (win >= a.N) {
+#else
             if (win >= a.N ||
                 (second - best < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN)) {
+#endif
                 // ambiguous and possibly within the threshold: exact scan,
                 // lowest index wins exact ties (the oracle's rule)
                 d2 = INFINITY;
@@ -756,10 +768,10 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
             uniform = 0;
     }
     h.uniform = uniform;
-    // uniform keys: t * (sqrt(weight) - sum) >= 0 for a unit trace, with a
-    // little head room for the rounding of the norm
-    h.key_c = (float)((h.KB == 16 ? 1.0 : 0.5) * std::sqrt((double)__builtin_popcount(mask[0])) *
-                      (1.0 + 0x1p-18));
+    // a uniform key (-t * sum) is t / v = t * sqrt(weight) times the score
+    h.key_c = 0.0f;
+    h.key_scale =
+        (float)((h.KB == 16 ? 1.0 : 0.5) * std::sqrt((double)__builtin_popcount(mask[0])));
     std::memcpy(blob.data(), &h, sizeof(h));
     MF_HIP_CHECK(hipMemcpy(table, blob.data(), (size_t)h.total, hipMemcpyHostToDevice));
     return uniform ? MF_CODEBOOK_UNIFORM : 0;
