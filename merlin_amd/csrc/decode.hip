@@ -214,6 +214,10 @@ decode_kernel(const DecodeArgs a)
     const uint32_t *g_mask = reinterpret_cast<const uint32_t *>(a.cbt + a.off_mask);
     const double *g_v64 = reinterpret_cast<const double *>(a.cbt + a.off_v64);
     const float key_scale = reinterpret_cast<const CbHeader *>(a.cbt)->key_scale;
+    // 64-byte table rows (more than 16 bits): the four 16-byte pieces of row n
+    // are stored at piece ^ ((n >> 2) & 3), which spreads the 32 rows one
+    // ds_read_b128 touches over all LDS banks (mf_codebook_prepare)
+    const int a_swz = MAXB == 32 ? ((lane & 31) >> 2) & 3 : 0;
 
     auto load_chunk = [&](int c0, int cn) {   // cn multiple of 32
         const u32x4 *src = reinterpret_cast<const u32x4 *>(a.cbt + a.off_a + (size_t)c0 * MAXB * 2);
@@ -467,7 +471,8 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         af[ks] = *reinterpret_cast<const u32x4 *>(
-                            lds_a + ((size_t)(ct + (lane & 31)) * MAXB + 16 * ks + 8 * half) * 2);
+                            lds_a + ((size_t)(ct + (lane & 31)) * MAXB +
+                                     8 * ((2 * ks + half) ^ a_swz)) * 2);
                     // both pixel tiles first, so the second chain of MFMAs
                     // runs under the first tile's epilogue
                     f32x16 acc[2];
@@ -614,9 +619,17 @@ int launch(DecodeArgs &a, hipStream_t stream)
 
     const size_t hs_bytes = (size_t)GROUP * RH * TW * sizeof(HT);
     const size_t per_word = (size_t)MAXB * 2 + 8;
-    const size_t budget = 96 * 1024;
+    // two workgroups per CU (160 KB of LDS): the second wave on every SIMD is
+    // what overlaps one wave's MFMA chain with the other's key reduction
+    const size_t budget = 80 * 1024;
     int chunk = (int)((budget - hs_bytes - 384) / per_word) & ~31;
-    if (chunk > a.Npad) chunk = a.Npad;
+    if (chunk >= a.Npad) {
+        chunk = a.Npad;
+    } else {
+        // equal chunks, each a multiple of 32 codewords
+        const int n_chunks = (a.Npad + chunk - 1) / chunk;
+        chunk = ((a.Npad / 32 + n_chunks - 1) / n_chunks) * 32;
+    }
     a.chunk = chunk;
     const size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * sizeof(float);
 
@@ -753,7 +766,10 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
                 v = c;
                 m |= 1u << b;
                 // bf16 -1.0, or -0.5 above 16 bits
-                am[(size_t)n * h.KB + b] = h.KB == 16 ? 0xbf80 : 0xbf00;
+                if (h.KB == 16)
+                    am[(size_t)n * 16 + b] = 0xbf80;
+                else        // swizzled 16-byte pieces, see a_swz in the kernel
+                    am[(size_t)n * 32 + 8 * ((b >> 3) ^ ((n >> 2) & 3)) + (b & 7)] = 0xbf00;
             }
             sq += c * c;
         }

@@ -192,7 +192,7 @@ def test_decode_random_scale_factors(seed, gpu_device):
                                   'b32_n1500_mixed', 'b12_n1'])
 def test_large_and_odd_codebooks(case, gpu_device):
     """BASELINE configs 3 and 5 at oracle-sized images: 22-bit codebooks (MHD4,
-    and 1000 distinct weight-4 words: one LDS chunk), 32-bit codebooks that exceed the LDS
+    and 1000 distinct weight-4 words: two LDS chunks), 32-bit codebooks that exceed the LDS
     budget and stream through it in chunks (uniform weight and mixed weight),
     and the degenerate one-codeword codebook."""
     from conftest import synth_stack
