@@ -527,10 +527,21 @@ region_stats(const StatsArgs a)
     }
 }
 
-// ~2e5 regions with <= 18 key bits: three onesweep passes beat rocPRIM's
-// default choice for this size (a block sort plus ~18 merge launches)
-using RegionSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                    rocprim::default_config, 4096>;
+// Onesweep with 9-bit digits (512-thread blocks): a pass costs ~45 us here
+// almost regardless of the element count, so the number of passes is what
+// matters -- 3 instead of 4 for the <= 27-bit pixel keys, 2 instead of 3 for
+// the <= 18-bit region keys.  (rocPRIM's default for ~2e5 elements would be a
+// block sort plus ~18 merge launches: the 4096 limit forces onesweep.)
+#ifndef MF_RADIX_BITS
+#define MF_RADIX_BITS 9
+#endif
+using Onesweep9 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<(1 << MF_RADIX_BITS), 8>,
+                                                      rocprim::kernel_config<(1 << MF_RADIX_BITS), 8>,
+                                                      MF_RADIX_BITS,
+                                                      rocprim::block_radix_rank_algorithm::match>;
+using PixelSortConfig =
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, Onesweep9, 4096>;
+using RegionSortConfig = PixelSortConfig;
 
 // workspace carve-up shared by the size query and the call
 struct Plan {
@@ -558,7 +569,7 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     size_t t2 = 0, t4 = 0;
     // size queries (null temp storage): no work is enqueued
     hipError_t e;
-    e = rocprim::radix_sort_pairs(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr,
+    e = rocprim::radix_sort_pairs<PixelSortConfig>(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (int32_t *)nullptr, (int32_t *)nullptr, np, 0u,
                                   (unsigned)pl.root_bits);
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
@@ -786,8 +797,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
                        chunks, n_pixels, pix_a, keys_a);
     // 2. group them by root; the stable sort keeps raster order inside a
     //    region and leaves the regions in root (= label) order
-    MF_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys_a, keys_b, pix_a, pix_b,
-                                           (size_t)n_pixels, 0u, (unsigned)pl.root_bits, s));
+    MF_HIP_CHECK(rocprim::radix_sort_pairs<PixelSortConfig>(
+        temp, tb, keys_a, keys_b, pix_a, pix_b, (size_t)n_pixels, 0u, (unsigned)pl.root_bits, s));
     // 3. region starts
     hipLaunchKernelGGL(chunk_count<true>, dim3(pl.pix_chunks), dim3(NT), 0, s,
                        (const int16_t *)nullptr, keys_b, n_pixels, chunks);
