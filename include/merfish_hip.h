@@ -141,8 +141,8 @@ int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
  *            5 mean_distance  6 min_distance
  *            7 centroid z  8 centroid row (y)    9 centroid column (x)
  *            10 first-pixel linear index
- *            11 position of the row inside its (z plane, barcode) group: the
- *               DataFrame index the reference assigns (decoding.py:246-252)
+ *            11 reserved (0); the position of the row inside its (z plane,
+ *               barcode) group is worked out by mf_region_frame
  *   inten    f32 [n_regions, B]  per-bit mean of the normalised traces
  *   mean_tm  f32 [n_regions, B]  per-bit mean of trace*magnitude, or NULL
  *   min_tm   f32 [n_regions, B]  per-bit min  of trace*magnitude, or NULL

@@ -336,7 +336,6 @@ struct StatsArgs {
     const int32_t *pix;      // sorted by root, raster order inside a region
     const int32_t *offsets;  // [n_regions] first entry of each region, root order
     const int32_t *order;    // [n_regions] region emitted as row r
-    const uint32_t *rkeys;   // [n_regions] sorted (plane, barcode) keys of the rows
     int64_t tr_p;
     int64_t n_pix, n_reg;
     const int16_t *dec;
@@ -491,14 +490,6 @@ region_stats(const StatsArgs a)
     if (!a.conn3d) cz = zfirst;
 
     if (sub == 0) {
-        // position inside the (plane, barcode) group: rows are sorted by that
-        // key, so it is r minus the first row carrying the key
-        const uint32_t key = a.rkeys[r];
-        int64_t lo = 0, hi = r;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (a.rkeys[mid] < key) lo = mid + 1; else hi = mid;
-        }
         double *row = a.rec + r * MF_REC_COLS;
         row[0] = (double)a.dec[first];
         row[1] = (double)zfirst;
@@ -511,7 +502,7 @@ region_stats(const StatsArgs a)
         row[8] = cy;
         row[9] = cx;
         row[10] = (double)first;
-        row[11] = (double)(r - lo);
+        row[11] = 0.0;      // reserved (the index inside the group: mf_region_frame)
     }
     // per-bit means: sequential float32 sums in raster order, then / n
     // (np.mean(list of f32 rows, axis 0), decoding.py:197, 220, 330)
@@ -611,29 +602,45 @@ struct KeepRow {
     }
 };
 
+// Position of every row inside its (z plane, barcode) group -- the DataFrame
+// index the reference ends up with, since it builds one frame per plane and
+// barcode (decoding.py:246-252, decode.py:225-230).  Rows are sorted by that
+// key: a binary search for the group's first row.  2-D key = (column 1,
+// column 0), 3-D key = column 0.
+__global__ void __launch_bounds__(NT)
+group_index(const double *__restrict__ rec, int64_t n, int conn3d, int32_t *__restrict__ idx)
+{
+    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (r >= n) return;
+    const double kb = rec[r * MF_REC_COLS], kz = conn3d ? 0.0 : rec[r * MF_REC_COLS + 1];
+    int64_t lo = 0, hi = r;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const double mb = rec[mid * MF_REC_COLS], mz = conn3d ? 0.0 : rec[mid * MF_REC_COLS + 1];
+        if (mz < kz || (mz == kz && mb < kb)) lo = mid + 1; else hi = mid;
+    }
+    idx[r] = (int32_t)(r - lo);
+}
+
 // column-major gather of the kept rows; `count` was written by the select.
-// The stores cross PCIe when the outputs are pinned host memory, so a wave
-// lives long, and every CU it sits on loses a workgroup slot of the decode
-// kernel running beside it on another stream (that kernel needs all 512
-// VGPRs of a SIMD for its two waves).  Hence few, large workgroups: four
-// 1024-thread groups saturate the link and touch only four CUs (measured per
-// 7-z FOV: 1 WG 4.64 ms, 2: 3.56, 4: 3.35, 8: 3.49, 16: 3.63; 48x256: 3.64).
 constexpr int GATHER_NT = 1024;
 
 __global__ void __launch_bounds__(GATHER_NT)
 frame_gather(const double *__restrict__ rec, const float *__restrict__ inten,
-             const int32_t *__restrict__ sel, const unsigned long long *__restrict__ count,
+             const int32_t *__restrict__ sel, const int32_t *__restrict__ gidx,
+             const unsigned long long *__restrict__ count,
              int64_t n_reg, int B, int zcol, double *__restrict__ out64,
              float *__restrict__ out32)
 {
     const int64_t m = (int64_t)*count;
-    const int cols[MF_FRAME_COLS] = {0, 3, 4, 2, 5, 6, 9, 8, zcol, 11};
+    const int cols[MF_FRAME_COLS - 1] = {0, 3, 4, 2, 5, 6, 9, 8, zcol};
     for (int64_t i = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x; i < m;
          i += (int64_t)gridDim.x * GATHER_NT) {
         const int64_t r = sel[i];
         const double *row = rec + r * MF_REC_COLS;
 #pragma unroll
-        for (int c = 0; c < MF_FRAME_COLS; ++c) out64[(int64_t)c * n_reg + i] = row[cols[c]];
+        for (int c = 0; c < MF_FRAME_COLS - 1; ++c) out64[(int64_t)c * n_reg + i] = row[cols[c]];
+        out64[(int64_t)(MF_FRAME_COLS - 1) * n_reg + i] = (double)gidx[r];
         for (int b = 0; b < B; ++b) out32[(int64_t)b * n_reg + i] = inten[r * B + b];
     }
 }
@@ -663,7 +670,7 @@ extern "C" int64_t mf_region_frame_workspace_bytes(int64_t n_regions)
         rocprim::select(nullptr, t, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
                         (unsigned long long *)nullptr, nr, KeepRow{nullptr, 0, 0, 0, 0});
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
-    return (int64_t)(align_up(nr * 4) + 256 + align_up(t));
+    return (int64_t)(2 * align_up(nr * 4) + 256 + align_up(t));
 }
 
 extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_regions, int B,
@@ -695,9 +702,13 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
     if ((rc = device_view(out64, &d64, "out64")) || (rc = device_view(out32, &d32, "out32")))
         return rc;
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    const size_t col = align_up((size_t)n_regions * 4);
     int32_t *sel = reinterpret_cast<int32_t *>(ws);
-    void *temp = ws + align_up((size_t)n_regions * 4) + 256;
-    size_t tb = (size_t)need - align_up((size_t)n_regions * 4) - 256;
+    int32_t *gidx = reinterpret_cast<int32_t *>(ws + col);
+    void *temp = ws + 2 * col + 256;
+    size_t tb = (size_t)need - 2 * col - 256;
+    hipLaunchKernelGGL(group_index, dim3((unsigned)((n_regions + NT - 1) / NT)), dim3(NT), 0, s, rec,
+                       n_regions, conn3d, gidx);
     // exclusive crop on the centroid with the reference's quirk: x is compared
     // with shape[0] and y with shape[1] (decoding.py:244)
     const KeepRow keep{rec, crop_width, crop_shape0 - crop_width, crop_shape1 - crop_width,
@@ -708,7 +719,7 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
     unsigned g = (unsigned)((n_regions + GATHER_NT - 1) / GATHER_NT);
     if (g > 4u) g = 4u;
     if (const char *e = std::getenv("MF_GATHER_WGS")) g = (unsigned)std::atoi(e);   // tuning aid
-    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel,
+    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel, gidx,
                        reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
                        conn3d ? 7 : 1, d64, d32);
     MF_HIP_CHECK(hipGetLastError());
@@ -817,7 +828,7 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
         (unsigned)pl.region_key_bits, s));
     // 5. per-region rows
     StatsArgs a;
-    a.pix = pix_b; a.offsets = offsets; a.order = ridx_b; a.rkeys = rkeys_b; a.n_pix = n_pixels; a.n_reg = n_regions;
+    a.pix = pix_b; a.offsets = offsets; a.order = ridx_b; a.n_pix = n_pixels; a.n_reg = n_regions;
     a.dec = decoded; a.mag = magnitudes; a.dist = distances;
     a.dist_f64 = dist_dtype == MF_DTYPE_F64;
     a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride; a.tr_p = tr_pix_stride;
