@@ -55,61 +55,159 @@ __device__ __forceinline__ void unite(int32_t *L, int a, int b)
     }
 }
 
-// ccl_init / ccl_merge run on a (ceil(W/256), H, Z) grid: x, y, z come from
-// the block indices, no integer division per pixel.
-//
-// Initial labels: every pixel of a horizontal run (same barcode, same row,
-// inside one 64-pixel wave segment) points at the run's first pixel, found
-// with a ballot -- the intra-row links cost no atomics at all.
-__global__ void __launch_bounds__(NT)
-ccl_init(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int H, int W)
+// ---- tile-local labelling -------------------------------------------------
+// A 64 x 32 tile per workgroup, labelled completely inside LDS: lane = column,
+// wave w owns rows 8w .. 8w+7.  Every pixel of a horizontal run first points
+// at the run's first pixel (one ballot per row, no atomics); a run is then
+// united with the runs it touches in the row above only where it FIRST touches
+// them (with N unless W and NW match -- the W pixel made that link; without N,
+// with NW unless W matches, and with NE), by atomicMin on LDS labels.  The
+// tile's components leave with the global raster index of their first pixel
+// in the tile as label; ccl_border then makes the few links that cross a tile
+// edge in global memory.  (One global union-find over all pixels, the previous
+// design, spent 0.28 ms per 7-z FOV waiting on dependent L2 round trips.)
+constexpr int CT_W = 64, CT_H = 32, CT_ROWS = CT_H / (NT / 64);
+
+__device__ __forceinline__ int lds_find(const int *lab, int x)
 {
-    const int x = blockIdx.x * NT + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int i = ((int)blockIdx.z * H + (int)blockIdx.y) * W + x;
-    const int code = x < W ? (int)dec[i] : -1;
-    const int prev = __shfl_up(code, 1);
-    const bool cont = code >= 0 && lane > 0 && prev == code;
-    const unsigned long long breaks = __ballot(!cont);          // bit 0 is always set
-    const unsigned long long upto = breaks & (~0ull >> (63 - lane));
-    const int start = 63 - __clzll((long long)upto);
-    if (x < W) L[i] = code >= 0 ? i - (lane - start) : -1;
+    int p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return x;
+}
+
+__device__ __forceinline__ void lds_unite(int *lab, int a, int b)
+{
+    for (;;) {
+        a = lds_find(lab, a);
+        b = lds_find(lab, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(lab + a, b);
+        if (old == a) return;
+        a = old;
+    }
 }
 
 __global__ void __launch_bounds__(NT)
-ccl_merge(const int16_t *__restrict__ dec, int32_t *L, int H, int W, int conn3d)
+ccl_tile(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int H, int W)
 {
-    const int x = blockIdx.x * NT + threadIdx.x;
-    if (x >= W) return;
-    const int y = blockIdx.y, z = blockIdx.z;
+    __shared__ int16_t s_code[CT_H][CT_W];
+    __shared__ int s_lab[CT_H * CT_W];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * CT_W + lane;
+    const int y0 = blockIdx.y * CT_H + wave * CT_ROWS;
+    const int64_t plane = (int64_t)blockIdx.z * H * W;
+
+    int code[CT_ROWS];
+    bool cont[CT_ROWS];       // same barcode as the pixel to the left, in this tile
+#pragma unroll
+    for (int r = 0; r < CT_ROWS; ++r) {
+        const int y = y0 + r, ly = wave * CT_ROWS + r;
+        code[r] = x < W && y < H ? (int)dec[plane + (int64_t)y * W + x] : -1;
+        s_code[ly][lane] = (int16_t)code[r];
+        const int prev = __shfl_up(code[r], 1);
+        cont[r] = code[r] >= 0 && lane > 0 && prev == code[r];
+        const unsigned long long breaks = __ballot(!cont[r]);       // bit 0 is always set
+        const unsigned long long upto = breaks & (~0ull >> (63 - lane));
+        const int start = 63 - __clzll((long long)upto);
+        s_lab[ly * CT_W + lane] = code[r] >= 0 ? ly * CT_W + start : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CT_ROWS; ++r) {
+        const int ly = wave * CT_ROWS + r;
+        if (code[r] < 0 || ly == 0) continue;
+        const int i = ly * CT_W + lane;
+        const int c = code[r];
+        const bool n = s_code[ly - 1][lane] == c;
+        const bool nw = lane > 0 && s_code[ly - 1][lane - 1] == c;
+        const bool ne = lane < CT_W - 1 && s_code[ly - 1][lane + 1] == c;
+        if (n) {
+            if (!(cont[r] && nw)) lds_unite(s_lab, i, i - CT_W);
+        } else {
+            if (nw && !cont[r]) lds_unite(s_lab, i, i - CT_W - 1);
+            if (ne) lds_unite(s_lab, i, i - CT_W + 1);
+        }
+    }
+    __syncthreads();
+    const int base = (int)plane + blockIdx.y * CT_H * W + blockIdx.x * CT_W;
+#pragma unroll
+    for (int r = 0; r < CT_ROWS; ++r) {
+        const int y = y0 + r, ly = wave * CT_ROWS + r;
+        if (x >= W || y >= H) continue;
+        int out = -1;
+        if (code[r] >= 0) {
+            const int root = lds_find(s_lab, ly * CT_W + lane);
+            out = base + (root / CT_W) * W + (root % CT_W);
+        }
+        L[plane + (int64_t)y * W + x] = out;
+    }
+}
+
+// the backward links of one pixel (W at a tile's left edge, NW, N, NE), with
+// the same first-touch rule as ccl_tile, in global memory
+__device__ __forceinline__ void merge_pixel(const int16_t *__restrict__ dec, int32_t *L, int x,
+                                            int y, int z, int H, int W)
+{
     const int i = (z * H + y) * W + x;
     const int16_t code = dec[i];
     if (code < 0) return;
-    // Same plane, backward neighbours W, NW, N, NE.  Runs are already linked,
-    // so a union is needed only where a run first touches a run of the row
-    // above: with N, unless W and NW match (then the W pixel made that link);
-    // without N, with NW unless W matches, and with NE.  A run cut by the
-    // 64-pixel segment boundary is re-joined at its lane 0.
     const bool w = x > 0 && dec[i - 1] == code;
     const bool n = y > 0 && dec[i - W] == code;
     const bool nw = y > 0 && x > 0 && dec[i - W - 1] == code;
     const bool ne = y > 0 && x + 1 < W && dec[i - W + 1] == code;
-    if (w && (threadIdx.x & 63) == 0) unite(L, i, i - 1);
+    if (w && x % CT_W == 0) unite(L, i, i - 1);
     if (n) {
         if (!(w && nw)) unite(L, i, i - W);
     } else {
         if (nw && !w) unite(L, i, i - W - 1);
         if (ne) unite(L, i, i - W + 1);
     }
-    if (conn3d && z > 0) {
-        const int base = i - W * H;
-        for (int dy = -1; dy <= 1; ++dy) {
-            if (y + dy < 0 || y + dy >= H) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (x + dx < 0 || x + dx >= W) continue;
-                const int q = base + dy * W + dx;
-                if (dec[q] == code) unite(L, i, q);
-            }
+}
+
+// Links across tile edges.  blockIdx.y < n_edge_rows: the pixels of a tile's
+// top row (y = 32 k, k >= 1); else the pixels of the tiles' left and right
+// columns (x = 64 k and 64 k + 63), one thread per (row, column) pair.  A link
+// that stays inside a tile is found already made and costs two label loads.
+__global__ void __launch_bounds__(NT)
+ccl_border(const int16_t *__restrict__ dec, int32_t *L, int H, int W, int n_edge_rows,
+           int n_edge_cols)
+{
+    const int z = blockIdx.z;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if ((int)blockIdx.y < n_edge_rows) {
+        if (t < W) merge_pixel(dec, L, t, ((int)blockIdx.y + 1) * CT_H, z, H, W);
+    } else {
+        const int row0 = ((int)blockIdx.y - n_edge_rows) * NT;   // NT rows per block row
+        // thread t of the x-blocks: column pair index, row inside the slab
+        const int col = t % n_edge_cols, y = row0 + t / n_edge_cols;
+        const int x = (col >> 1) * CT_W + (col & 1 ? CT_W - 1 : 0);
+        // (a tile's top row belongs to the edge rows above, except image row 0)
+        if (t / n_edge_cols < NT && y < H && x < W && (y % CT_H != 0 || y == 0))
+            merge_pixel(dec, L, x, y, z, H, W);
+    }
+}
+
+// 26-connectivity: links to the nine neighbours in the plane below
+__global__ void __launch_bounds__(NT)
+ccl_merge_z(const int16_t *__restrict__ dec, int32_t *L, int H, int W)
+{
+    const int x = blockIdx.x * NT + threadIdx.x;
+    if (x >= W) return;
+    const int y = blockIdx.y, z = blockIdx.z + 1;
+    const int i = (z * H + y) * W + x;
+    const int16_t code = dec[i];
+    if (code < 0) return;
+    const int base = i - W * H;
+    for (int dy = -1; dy <= 1; ++dy) {
+        if (y + dy < 0 || y + dy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (x + dx < 0 || x + dx >= W) continue;
+            const int q = base + dy * W + dx;
+            if (dec[q] == code) unite(L, i, q);
         }
     }
 }
@@ -740,9 +838,24 @@ extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, 
     const unsigned grid = (unsigned)((n + NT - 1) / NT);
     if (H > 65535 || Z > 65535) return mf::fail(MF_EUNSUPPORTED, "H and Z must be <= 65535");
     MF_HIP_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(int64_t), s));
-    const dim3 g3((unsigned)((W + NT - 1) / NT), (unsigned)H, (unsigned)Z);
-    hipLaunchKernelGGL(ccl_init, g3, dim3(NT), 0, s, decoded, labels, H, W);
-    hipLaunchKernelGGL(ccl_merge, g3, dim3(NT), 0, s, decoded, labels, H, W, conn3d);
+    const int tiles_x = (W + CT_W - 1) / CT_W, tiles_y = (H + CT_H - 1) / CT_H;
+    hipLaunchKernelGGL(ccl_tile, dim3((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)Z), dim3(NT), 0,
+                       s, decoded, labels, H, W);
+    {
+        // edge rows: one block row per tile edge, W threads; edge columns:
+        // 2 per tile column, slabs of NT image rows
+        const int n_edge_rows = tiles_y - 1, n_edge_cols = 2 * tiles_x;
+        const int slabs = (H + NT - 1) / NT;
+        const int need_x = W > NT * n_edge_cols ? W : NT * n_edge_cols;
+        hipLaunchKernelGGL(ccl_border,
+                           dim3((unsigned)((need_x + NT - 1) / NT), (unsigned)(n_edge_rows + slabs),
+                                (unsigned)Z),
+                           dim3(NT), 0, s, decoded, labels, H, W, n_edge_rows, n_edge_cols);
+    }
+    if (conn3d && Z > 1)
+        hipLaunchKernelGGL(ccl_merge_z,
+                           dim3((unsigned)((W + NT - 1) / NT), (unsigned)H, (unsigned)(Z - 1)),
+                           dim3(NT), 0, s, decoded, labels, H, W);
     const unsigned fgrid = grid < 2048u ? grid : 2048u;
     hipLaunchKernelGGL(ccl_flatten, dim3(fgrid), dim3(NT), 0, s, labels, n,
                        reinterpret_cast<unsigned long long *>(counts));
