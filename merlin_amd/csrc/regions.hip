@@ -349,16 +349,23 @@ chunk_count(const int16_t *__restrict__ dec, const uint32_t *__restrict__ keys, 
 }
 
 // in-place exclusive scan of the chunk counts by ONE block; thread t owns a
-// contiguous slice
+// contiguous slice of `per` counts (a multiple of 4, read as independent
+// 16-byte loads: the kernel is pure latency)
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
 chunk_scan(int32_t *counts, int n_chunks)
 {
     __shared__ int s_wave[SCAN_NT / 64];
-    const int per = (n_chunks + SCAN_NT - 1) / SCAN_NT;
+    const int per = ((n_chunks + SCAN_NT - 1) / SCAN_NT + 3) & ~3;
     const int lo = min(n_chunks, (int)threadIdx.x * per), hi = min(n_chunks, lo + per);
+    const int hi4 = lo + ((hi - lo) & ~3);
     int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += counts[i];
+#pragma unroll 8
+    for (int i = lo; i < hi4; i += 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(counts + i);
+        sum += v.x + v.y + v.z + v.w;
+    }
+    for (int i = hi4; i < hi; ++i) sum += counts[i];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = sum;
 #pragma unroll
@@ -371,7 +378,14 @@ chunk_scan(int32_t *counts, int n_chunks)
     int base = 0;
     for (int j = 0; j < w; ++j) base += s_wave[j];
     int run = base + inc - sum;
-    for (int i = lo; i < hi; ++i) {
+#pragma unroll 8
+    for (int i = lo; i < hi4; i += 4) {
+        int4 v = *reinterpret_cast<const int4 *>(counts + i);
+        const int a = run, b = a + v.x, c = b + v.y, d = c + v.z;
+        run = d + v.w;
+        *reinterpret_cast<int4 *>(counts + i) = make_int4(a, b, c, d);
+    }
+    for (int i = hi4; i < hi; ++i) {
         const int c = counts[i];
         counts[i] = run;
         run += c;
