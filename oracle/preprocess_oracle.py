@@ -1,0 +1,168 @@
+"""CPU oracle for the preprocess stage.  TEST INFRASTRUCTURE ONLY.
+
+numpy restatement of what produces the decoder's uint16 stack in the reference
+(emanuega/MERlin v0.1.6).  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of the dev/bench scripts may import it; nothing under
+``merlin_amd/`` does.
+
+Reference files restated (file:line of /root/reference):
+
+* ``merlin/util/imagefilters.py:9-28``     high_pass_filter
+* ``merlin/util/deconvolve.py:70-133``     deconvolve_lucyrichardson (odd window)
+* ``merlin/analysis/preprocess.py:103-108, 133-140``  _high_pass_filter,
+  _preprocess_image (``.astype(np.uint16)`` of the float64 result)
+* ``merlin/analysis/preprocess.py:114-129``  per-bit pixel histogram
+
+Third-party arithmetic not under /root/reference, restated from OpenCV 4.x's
+published sources (opencv-python>=3 is unpinned in requirements.txt:6; cv2 is
+absent from this container, so these stages are **parity unpinned**):
+
+* ``cv2.GaussianBlur`` on CV_16U, BORDER_REPLICATE: the bit-exact fixed-point
+  path (16.16 taps with error diffusion, exact u32 / u64 sums,
+  ``(acc + 2**31) >> 32``), as in ``merfish_oracle.gaussian_blur_u16`` but with
+  the replicated border.
+* ``cv2.GaussianBlur`` on CV_64F, BORDER_REPLICATE: ``sepFilter2D`` with the
+  float64 kernel of getGaussianKernel.  Row pass = generic ``RowFilter``:
+  ``s = k[0]*S[0]; s += k[j]*S[j]`` left to right.  Column pass =
+  ``SymmColumnFilter``: ``s = k[c]*S[c]; s += k[c+j]*(S[c+j] + S[c-j])``.
+  Every product and sum is rounded on its own (no fused multiply-add; an
+  AVX2/FMA build of OpenCV may differ in the last ulp).
+* ``cv2.subtract / addWeighted / multiply / divide`` on CV_64F: the plain
+  float64 operation per element (``addWeighted`` = ``a*alpha + b*beta + gamma``).
+
+Everything AROUND those calls (the Lucy-Richardson loop, its acceleration
+parameter, the clipping and the uint16 hand-over) is pinned by golden vectors
+made by the reference's own ``deconvolve.py`` / ``imagefilters.py``
+(``oracle/make_preprocess_goldens.py``, ``tests/golden/pp_*.npz``).
+"""
+import numpy as np
+
+from merfish_oracle import gaussian_kernel_f64, gaussian_kernel_fixed16
+
+
+def filter_size_for_sigma(sigma: float) -> int:
+    """preprocess.py:50-51, 104"""
+    return int(2 * np.ceil(2 * sigma) + 1)
+
+
+def gaussian_blur_u16_replicate(img: np.ndarray, ksize: int,
+                                sigma: float) -> np.ndarray:
+    """Exact integer separable blur of one uint16 plane, BORDER_REPLICATE."""
+    assert img.dtype == np.uint16 and img.ndim == 2
+    if ksize == 1:
+        return img.copy()
+    k = gaussian_kernel_fixed16(ksize, sigma).astype(np.uint64)
+    r = ksize // 2
+    h, w = img.shape
+    p = np.pad(img.astype(np.uint64), r, mode='edge')
+    hs = np.zeros((h + 2 * r, w), dtype=np.uint64)
+    for j in range(ksize):
+        hs += k[j] * p[:, j:j + w]
+    vs = np.zeros((h, w), dtype=np.uint64)
+    for j in range(ksize):
+        vs += k[j] * hs[j:j + h, :]
+    out = (vs + np.uint64(1 << 31)) >> np.uint64(32)
+    return np.minimum(out, 65535).astype(np.uint16)
+
+
+def gaussian_blur_f64_replicate(img: np.ndarray, ksize: int,
+                                sigma: float) -> np.ndarray:
+    """cv2.GaussianBlur on float64, BORDER_REPLICATE (see the module header for
+    the summation order)."""
+    assert img.dtype == np.float64 and img.ndim == 2
+    if ksize == 1:
+        return img.copy()
+    k = gaussian_kernel_f64(ksize, sigma)
+    r = ksize // 2
+    h, w = img.shape
+    p = np.pad(img, r, mode='edge')
+    hs = k[0] * p[:, 0:w]
+    for j in range(1, ksize):
+        hs = hs + k[j] * p[:, j:j + w]
+    vs = k[r] * hs[r:r + h, :]
+    for j in range(1, r + 1):
+        vs = vs + k[r + j] * (hs[r + j:r + j + h, :] + hs[r - j:r - j + h, :])
+    return vs
+
+
+def high_pass_filter(image: np.ndarray, windowSize: int,
+                     sigma: float) -> np.ndarray:
+    """imagefilters.py:9-28 for uint16 input: the wrapped uint16 difference,
+    zeroed where the low-pass exceeds the image."""
+    assert image.dtype == np.uint16
+    lowpass = gaussian_blur_u16_replicate(image, windowSize, sigma)
+    hp = image - lowpass                      # uint16 arithmetic wraps
+    hp[lowpass > image] = 0
+    return hp
+
+
+def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
+                              sigmaG: float, iterationCount: int,
+                              trace: list = None) -> np.ndarray:
+    """deconvolve.py:70-133, odd windowSize (the cv2.GaussianBlur branch).
+    ``trace`` (optional list) receives the acceleration parameter of every
+    iteration."""
+    if windowSize % 2 != 1:
+        raise NotImplementedError('even window sizes take the ndimage path')
+    image = np.asarray(image, dtype=np.float64)
+    eps = np.finfo(float).eps
+    Y = np.copy(image)
+    J1 = np.copy(image)
+    J2 = np.copy(image)
+    wI = np.copy(image)
+    T1 = np.zeros(image.shape, dtype=float)
+    T2 = np.zeros(image.shape, dtype=float)
+    lam = 0
+    for i in range(iterationCount):
+        if i > 1:
+            lam = np.sum(T1 * T2) / (np.sum(T2 * T2) + eps)
+            lam = max(min(lam, 1), 0)
+        if trace is not None:
+            trace.append(float(lam))
+        Y = J1 - J2                           # cv2.subtract
+        Y = J1 * 1.0 + Y * float(lam) + 0.0   # cv2.addWeighted
+        np.clip(Y, 0, None, Y)
+        reblurred = gaussian_blur_f64_replicate(Y, windowSize, sigmaG)
+        np.clip(reblurred, eps, None, reblurred)
+        imR = wI / reblurred                  # cv2.divide (divisor never 0)
+        imR += eps
+        imR = gaussian_blur_f64_replicate(imR, windowSize, sigmaG)
+        J2 = J1
+        J1 = Y * imR
+        T2 = T1
+        T1 = J1 - Y
+    return J1
+
+
+def to_uint16(values: np.ndarray) -> np.ndarray:
+    """``float64.astype(np.uint16)`` as x86 numpy builds do it: truncate toward
+    zero to int32 (cvttsd2si; out of range or NaN gives 0x80000000) and keep
+    the low 16 bits."""
+    v = np.asarray(values, dtype=np.float64)
+    ok = np.isfinite(v) & (np.abs(v) < 2147483648.0)
+    t = np.where(ok, np.trunc(np.where(ok, v, 0.0)), 0.0).astype(np.int64)
+    return (t & 0xffff).astype(np.uint16)
+
+
+def preprocess_image(inputImage: np.ndarray, highpass_sigma: float = 3,
+                     decon_sigma: float = 2, decon_filter_size: int = None,
+                     decon_iterations: int = 20) -> np.ndarray:
+    """DeconvolutionPreprocess._preprocess_image (preprocess.py:133-140) with
+    the defaults of ``__init__`` (:45-53)."""
+    if decon_filter_size is None:
+        decon_filter_size = filter_size_for_sigma(decon_sigma)
+    hp = high_pass_filter(inputImage, filter_size_for_sigma(highpass_sigma),
+                          highpass_sigma).astype(np.float64)
+    return to_uint16(deconvolve_lucyrichardson(
+        hp, decon_filter_size, decon_sigma, decon_iterations))
+
+
+def pixel_histogram(images: np.ndarray) -> np.ndarray:
+    """preprocess.py:114-129 for the images of one bit: counts over the bins
+    ``np.arange(0, 65535)`` (65534 bins; the last one holds 65533 and 65534,
+    65535 falls outside)."""
+    v = np.asarray(images, dtype=np.uint16).ravel()
+    c = np.bincount(v, minlength=65536).astype(np.float64)
+    out = c[:65534].copy()
+    out[65533] += c[65534]
+    return out

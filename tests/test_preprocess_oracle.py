@@ -1,0 +1,87 @@
+"""Preprocess oracle (oracle/preprocess_oracle.py) against the golden vectors the
+reference's own deconvolve.py / imagefilters.py produced
+(oracle/make_preprocess_goldens.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+import preprocess_oracle as po
+
+PP_NAMES = sorted(os.path.basename(p)[:-4]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, 'pp_*.npz')))
+
+
+def load_pp(name):
+    g = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    d = {k: g[k] for k in g.files}
+    p = d['params']
+    d['p'] = dict(hp_sigma=float(p[0]), decon_sigma=float(p[1]),
+                  decon_size=int(p[2]), iterations=int(p[3]))
+    return d
+
+
+def test_goldens_present():
+    assert len(PP_NAMES) >= 6
+
+
+@pytest.mark.parametrize('name', PP_NAMES)
+def test_high_pass_bit_exact(name):
+    g = load_pp(name)
+    hp = po.high_pass_filter(g['image'],
+                             po.filter_size_for_sigma(g['p']['hp_sigma']),
+                             g['p']['hp_sigma'])
+    assert hp.dtype == np.uint16
+    assert np.array_equal(hp, g['highpass'])
+
+
+@pytest.mark.parametrize('name', PP_NAMES)
+def test_lucy_richardson_bit_exact(name):
+    # same primitives + the reference's own loop: identical float64 bits
+    g = load_pp(name)
+    p = g['p']
+    dec = po.deconvolve_lucyrichardson(g['highpass'].astype(np.float64),
+                                       p['decon_size'], p['decon_sigma'],
+                                       p['iterations'])
+    assert np.array_equal(dec, g['deconvolved'])
+    assert np.array_equal(po.to_uint16(dec), g['output'])
+
+
+@pytest.mark.parametrize('name', PP_NAMES)
+def test_preprocess_image_and_histogram(name):
+    g = load_pp(name)
+    p = g['p']
+    out = po.preprocess_image(g['image'], p['hp_sigma'], p['decon_sigma'],
+                              p['decon_size'], p['iterations'])
+    assert out.dtype == np.uint16 and np.array_equal(out, g['output'])
+    assert np.array_equal(po.pixel_histogram(out), g['histogram'])
+
+
+def test_to_uint16_wraps_like_numpy_on_x86():
+    v = np.array([0.0, 0.999, 1.0, 65535.9, 65536.0, 70000.5, 194617.5, -0.5,
+                  -1.0, 2147483647.9, 2147483648.0, 1e300, np.nan, np.inf])
+    want = np.array([0, 0, 1, 65535, 0, 70000 - 65536, 194617 - 2 * 65536, 0,
+                     65535, 65535, 0, 0, 0, 0], dtype=np.uint16)
+    assert np.array_equal(po.to_uint16(v), want)
+
+
+def test_blur_known_answers():
+    # constant image: taps sum to exactly 65536 / 1.0, borders replicate
+    c = np.full((20, 24), 1234, dtype=np.uint16)
+    assert np.array_equal(po.gaussian_blur_u16_replicate(c, 13, 3.0), c)
+    f = po.gaussian_blur_f64_replicate(np.full((12, 12), 2.5), 9, 2.0)
+    assert np.allclose(f, 2.5, rtol=1e-15)
+    # impulse: the blur of a delta is the outer product of the taps
+    from merfish_oracle import gaussian_kernel_f64
+    d = np.zeros((21, 21))
+    d[10, 10] = 1.0
+    k = gaussian_kernel_f64(9, 2.0)
+    assert np.allclose(po.gaussian_blur_f64_replicate(d, 9, 2.0)[6:15, 6:15],
+                       np.outer(k, k), rtol=1e-14, atol=0)
+    # a step at the border stays a step (replicate, not reflect)
+    s = np.zeros((16, 16), dtype=np.uint16)
+    s[:, 0] = 60000
+    b = po.gaussian_blur_u16_replicate(s, 13, 3.0)
+    assert b[8, 0] > b[8, 1] > b[8, 6] > 0 and b[8, 7] == 0
