@@ -38,6 +38,8 @@ extern "C" {
 #define MF_MAX_RADIUS    4   /* blur radius: ksize <= 9, i.e. sigma <= 2    */
 #define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
 #define MF_FRAME_COLS   10   /* float64 columns of mf_region_frame          */
+#define MF_PP_MAX_RADIUS 8   /* preprocess high-pass radius: sigma <= 4     */
+#define MF_HIST_BINS 65534   /* bins of np.arange(0, 65535), preprocess.py:114 */
 
 #define MF_CODEBOOK_UNIFORM 1 /* flag: all codewords share weight and value   */
 
@@ -179,6 +181,61 @@ int mf_region_frame(const double *rec, const float *inten, int64_t n_regions,
                     double crop_shape1, double minimum_area,
                     double *out64, float *out32, int64_t *count,
                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* ---- preprocess stage: what produces the uint16 stack
+ * mf_decode_pixels reads.  Image batches are [n_images, H, W] row-major. ---- */
+
+/* high_pass_filter on uint16 (merlin/util/imagefilters.py:9-28 as called by
+ * DeconvolutionPreprocess._high_pass_filter, analysis/preprocess.py:103-108):
+ * low-pass = cv2.GaussianBlur(image, (window_size, window_size), sigma,
+ * BORDER_REPLICATE), window_size odd and <= 17, in OpenCV 4.x's exact
+ * fixed-point CV_16U arithmetic; out = image - lowpass, 0 where lowpass >
+ * image.  Not in place. */
+int mf_high_pass_filter(const uint16_t *image, int n_images, int H, int W,
+                        int window_size, double sigma, uint16_t *out,
+                        void *stream);
+
+/* Scratch for the two calls below; `batch` images are deconvolved together
+ * (34 B/px each: keep batch * H * W * 34 under the 256 MiB Infinity Cache). */
+int64_t mf_preprocess_workspace_bytes(int batch, int H, int W);
+
+/* deconvolve_lucyrichardson (merlin/util/deconvolve.py:70-133), odd
+ * window_size <= 13 (the cv2.GaussianBlur branch; BORDER_REPLICATE), float64
+ * arithmetic throughout like the reference.
+ *
+ *   image      u16 or f64 (image_dtype) [n_images,H,W]; not modified
+ *   out        f64 (the reference's return value) or u16 (out_dtype): the
+ *              `.astype(np.uint16)` of preprocess.py:139 (truncate toward
+ *              zero, wrap modulo 2^16); must not alias `image`
+ *   histogram  int64 [ceil(n_images/hist_group), MF_HIST_BINS] or NULL: counts
+ *              of the uint16 output over np.arange(0, 65535)
+ *              (preprocess.py:114-129) are ADDED to row image / hist_group;
+ *              the caller zeroes it.  uint16 output only.
+ *   lambdas    f64 [n_images, iterations] or NULL: the acceleration parameter
+ *              every iteration used (deconvolve.py:110-111), for checking
+ *   batch      images per pass; the workspace must hold
+ *              mf_preprocess_workspace_bytes(batch, H, W)
+ * The acceleration sums are reduced in a fixed order, so results are
+ * identical from run to run; they differ from numpy's pairwise np.sum in the
+ * last bits. */
+int mf_deconvolve_lucyrichardson(const void *image, int image_dtype,
+                                 int n_images, int H, int W, int window_size,
+                                 double sigma, int iterations, void *out,
+                                 int out_dtype, int64_t *histogram,
+                                 int hist_group, double *lambdas, int batch,
+                                 void *workspace, int64_t workspace_bytes,
+                                 void *stream);
+
+/* DeconvolutionPreprocess._preprocess_image (analysis/preprocess.py:133-140)
+ * for n_images camera frames: high-pass (highpass_sigma), Lucy-Richardson
+ * (decon_filter_size, decon_sigma, decon_iterations), uint16 hand-over, plus
+ * the pixel histogram of _run_analysis (:114-129) as above. */
+int mf_preprocess_images(const uint16_t *image, int n_images, int H, int W,
+                         double highpass_sigma, int decon_filter_size,
+                         double decon_sigma, int decon_iterations,
+                         uint16_t *out, int64_t *histogram, int hist_group,
+                         int batch, void *workspace, int64_t workspace_bytes,
+                         void *stream);
 
 #ifdef __cplusplus
 }

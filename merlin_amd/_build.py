@@ -16,7 +16,7 @@ INCLUDE = os.path.join(ROOT, 'include')
 BUILD = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libmerfish_hip.so')
 
-SOURCES = ['common.cpp', 'decode.hip', 'regions.hip']
+SOURCES = ['common.cpp', 'decode.hip', 'regions.hip', 'preprocess.hip']
 # -ffp-contract=off: the kernels reproduce numpy's unfused float arithmetic;
 # fused multiply-adds are written explicitly where they are wanted.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',

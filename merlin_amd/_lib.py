@@ -20,13 +20,17 @@ MF_MAX_RADIUS = 4
 MF_REC_COLS = 12
 MF_FRAME_COLS = 10
 MF_DECODE_TRACES_DECODED_ONLY = 1
+MF_PP_MAX_RADIUS = 8
+MF_HIST_BINS = 65534
 
 # every symbol include/merfish_hip.h declares
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
            'mf_codebook_table_bytes', 'mf_codebook_prepare',
            'mf_decode_pixels', 'mf_label_components',
            'mf_region_workspace_bytes', 'mf_region_table',
-           'mf_region_frame_workspace_bytes', 'mf_region_frame')
+           'mf_region_frame_workspace_bytes', 'mf_region_frame',
+           'mf_high_pass_filter', 'mf_preprocess_workspace_bytes',
+           'mf_deconvolve_lucyrichardson', 'mf_preprocess_images')
 
 _lib = None
 
@@ -76,6 +80,17 @@ def lib():
     L.mf_region_frame.restype = i32
     L.mf_region_frame.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64, f64,
                                   vp, vp, vp, vp, i64, vp]
+    L.mf_high_pass_filter.restype = i32
+    L.mf_high_pass_filter.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp]
+    L.mf_preprocess_workspace_bytes.restype = i64
+    L.mf_preprocess_workspace_bytes.argtypes = [i32, i32, i32]
+    L.mf_deconvolve_lucyrichardson.restype = i32
+    L.mf_deconvolve_lucyrichardson.argtypes = [
+        vp, i32, i32, i32, i32, i32, f64, i32, vp, i32, vp, i32, vp, i32, vp,
+        i64, vp]
+    L.mf_preprocess_images.restype = i32
+    L.mf_preprocess_images.argtypes = [
+        vp, i32, i32, i32, f64, i32, f64, i32, vp, vp, i32, i32, vp, i64, vp]
     _lib = L
     return L
 

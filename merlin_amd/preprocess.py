@@ -1,0 +1,229 @@
+"""MI355X preprocess stage: what produces the decoder's uint16 stack.
+
+Mirrors, for the image arithmetic only (no task framework, no data set I/O):
+
+* ``merlin/util/imagefilters.py:9-28``    ``high_pass_filter``
+* ``merlin/util/deconvolve.py:70-133``    ``deconvolve_lucyrichardson``
+* ``merlin/analysis/preprocess.py:40-140`` ``DeconvolutionPreprocess``:
+  parameter names and defaults, ``_high_pass_filter``, ``_preprocess_image``
+  and the per-bit pixel histogram of ``_run_analysis``.
+
+All arithmetic runs in libmerfish_hip.so (csrc/preprocess.hip).  There is no
+CPU fallback: without the library or a GPU the calls raise.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from merlin_amd import _lib
+
+HIST_BINS = _lib.MF_HIST_BINS
+# working set per pixel and image inside mf_deconvolve_lucyrichardson
+_BYTES_PER_PIXEL = 34
+_INFINITY_CACHE = 256 << 20
+
+
+def default_batch(H: int, W: int) -> int:
+    """Images deconvolved together: as many as keep the working set inside the
+    256 MiB Infinity Cache, at least one."""
+    return max(1, int(0.8 * _INFINITY_CACHE) // (_BYTES_PER_PIXEL * H * W))
+
+
+def _device(device=None):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise _lib.MerfishHipError(
+            'no GPU visible: merlin_amd has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_workspaces = {}
+
+
+def _workspace(device, batch, H, W):
+    nbytes = _lib.check(_lib.lib().mf_preprocess_workspace_bytes(batch, H, W))
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _as_images(t: torch.Tensor):
+    if t.dim() < 2:
+        raise ValueError('image must have at least two dimensions')
+    H, W = t.shape[-2:]
+    return t.reshape(-1, H, W).contiguous(), t.shape
+
+
+def high_pass_filter_device(image: torch.Tensor, windowSize: int,
+                            sigma: float) -> torch.Tensor:
+    """imagefilters.high_pass_filter for uint16 images [..., H, W] on the GPU."""
+    if image.dtype != torch.uint16:
+        raise NotImplementedError('high_pass_filter is built for uint16 images')
+    flat, shape = _as_images(image)
+    out = torch.empty_like(flat)
+    n, H, W = flat.shape
+    with torch.cuda.device(flat.device):
+        _lib.check(_lib.lib().mf_high_pass_filter(
+            flat.data_ptr(), n, H, W, int(windowSize), float(sigma),
+            out.data_ptr(), _stream_ptr(flat.device)))
+    return out.reshape(shape)
+
+
+def high_pass_filter(image: np.ndarray, windowSize: int,
+                     sigma: float) -> np.ndarray:
+    """Drop-in for merlin.util.imagefilters.high_pass_filter (uint16 in,
+    uint16 out, numpy)."""
+    image = np.asarray(image)
+    if image.dtype != np.uint16:
+        raise NotImplementedError('high_pass_filter is built for uint16 images')
+    dev = _device()
+    t = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
+    return high_pass_filter_device(t, windowSize, sigma).cpu().numpy()
+
+
+def deconvolve_lucyrichardson_device(
+        image: torch.Tensor, windowSize: int, sigmaG: float,
+        iterationCount: int, out_dtype=torch.float64,
+        histogram: Optional[torch.Tensor] = None, hist_group: int = 1,
+        batch: Optional[int] = None, return_lambdas: bool = False):
+    """deconvolve_lucyrichardson for images [..., H, W] (uint16 or float64) on
+    the GPU.  ``out_dtype`` float64 is the reference's return value, uint16 its
+    ``.astype(np.uint16)``.  ``histogram`` (int64 [rows, 65534], zeroed by the
+    caller) receives the counts of image i in row i // hist_group."""
+    if image.dtype == torch.uint16:
+        dt = _lib.MF_DTYPE_U16
+    elif image.dtype == torch.float64:
+        dt = _lib.MF_DTYPE_F64
+    else:
+        raise NotImplementedError('image must be uint16 or float64')
+    if out_dtype not in (torch.float64, torch.uint16):
+        raise ValueError('out_dtype must be float64 or uint16')
+    flat, shape = _as_images(image)
+    n, H, W = flat.shape
+    dev = flat.device
+    if batch is None:
+        batch = default_batch(H, W)
+    batch = max(1, min(int(batch), max(n, 1)))
+    out = torch.empty((n, H, W), dtype=out_dtype, device=dev)
+    lam = torch.zeros((n, max(int(iterationCount), 1)), dtype=torch.float64,
+                      device=dev) if return_lambdas else None
+    if histogram is not None:
+        rows = (n + hist_group - 1) // hist_group
+        if histogram.dtype != torch.int64 or not histogram.is_contiguous() or \
+                tuple(histogram.shape) != (rows, HIST_BINS):
+            raise ValueError('histogram must be contiguous int64 [{}, {}]'
+                             .format(rows, HIST_BINS))
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, batch, H, W)
+        _lib.check(_lib.lib().mf_deconvolve_lucyrichardson(
+            flat.data_ptr(), dt, n, H, W, int(windowSize), float(sigmaG),
+            int(iterationCount), out.data_ptr(),
+            _lib.MF_DTYPE_F64 if out_dtype == torch.float64 else _lib.MF_DTYPE_U16,
+            None if histogram is None else histogram.data_ptr(), int(hist_group),
+            None if lam is None else lam.data_ptr(), batch, ws.data_ptr(),
+            ws.numel(), _stream_ptr(dev)))
+    out = out.reshape(shape)
+    return (out, lam) if return_lambdas else out
+
+
+def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
+                              sigmaG: float,
+                              iterationCount: int) -> np.ndarray:
+    """Drop-in for merlin.util.deconvolve.deconvolve_lucyrichardson (float64
+    numpy in and out; odd windowSize)."""
+    dev = _device()
+    t = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float64)).to(dev)
+    return deconvolve_lucyrichardson_device(
+        t, windowSize, sigmaG, iterationCount).cpu().numpy()
+
+
+class DeconvolutionPreprocess(object):
+    """Image arithmetic of merlin.analysis.preprocess.DeconvolutionPreprocess.
+
+    ``parameters`` takes the reference's keys with the reference's defaults
+    (preprocess.py:45-53): highpass_sigma 3, decon_sigma 2, decon_filter_size
+    2*ceil(2*decon_sigma)+1, decon_iterations 20."""
+
+    def __init__(self, parameters=None, device=None, batch=None):
+        self.parameters = dict(parameters or {})
+        if 'highpass_sigma' not in self.parameters:
+            self.parameters['highpass_sigma'] = 3
+        if 'decon_sigma' not in self.parameters:
+            self.parameters['decon_sigma'] = 2
+        if 'decon_filter_size' not in self.parameters:
+            self.parameters['decon_filter_size'] = \
+                int(2 * np.ceil(2 * self.parameters['decon_sigma']) + 1)
+        if 'decon_iterations' not in self.parameters:
+            self.parameters['decon_iterations'] = 20
+        self._highPassSigma = self.parameters['highpass_sigma']
+        self._deconSigma = self.parameters['decon_sigma']
+        self._deconIterations = self.parameters['decon_iterations']
+        self._device = device
+        self._batch = batch
+
+    # ------------------------------------------------ reference-shaped API --
+
+    def _high_pass_filter(self, inputImage: np.ndarray) -> np.ndarray:
+        """preprocess.py:103-108 (returns float64 like the reference)."""
+        highPassFilterSize = int(2 * np.ceil(2 * self._highPassSigma) + 1)
+        hpImage = high_pass_filter(inputImage, highPassFilterSize,
+                                   self._highPassSigma)
+        return hpImage.astype(float)
+
+    def _preprocess_image(self, inputImage: np.ndarray) -> np.ndarray:
+        """preprocess.py:133-140: one camera frame -> uint16."""
+        inputImage = np.asarray(inputImage)
+        if inputImage.dtype != np.uint16:
+            raise NotImplementedError('camera frames must be uint16')
+        dev = _device(self._device)
+        t = torch.from_numpy(np.ascontiguousarray(inputImage)).to(dev)
+        out, _ = self.preprocess_device(t, histogram=False)
+        return out.cpu().numpy()
+
+    # ------------------------------------------------- device-resident API --
+
+    def preprocess_device(self, images: torch.Tensor, histogram: bool = True,
+                          hist_group: Optional[int] = None
+                          ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """``_preprocess_image`` for every uint16 image of ``images``
+        [..., H, W] on the GPU, e.g. the warped stack [B,Z,H,W] of one FOV:
+        the result is what ``get_processed_image_set`` returns
+        (preprocess.py:79-93) and what the decoder reads.
+
+        With ``histogram`` the second value is the int64 pixel histogram
+        [rows, 65534] of ``_run_analysis`` (preprocess.py:114-129);
+        ``hist_group`` images share a row (default: the length of the second
+        dimension of a 4-D stack, i.e. one row per bit)."""
+        if images.dtype != torch.uint16:
+            raise NotImplementedError('camera frames must be uint16')
+        flat, shape = _as_images(images)
+        n, H, W = flat.shape
+        dev = flat.device
+        batch = self._batch or default_batch(H, W)
+        batch = max(1, min(int(batch), max(n, 1)))
+        if hist_group is None:
+            hist_group = shape[1] if len(shape) == 4 else 1
+        out = torch.empty_like(flat)
+        hist = None
+        if histogram:
+            hist = torch.zeros(((n + hist_group - 1) // hist_group, HIST_BINS),
+                               dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            ws = _workspace(dev, batch, H, W)
+            _lib.check(_lib.lib().mf_preprocess_images(
+                flat.data_ptr(), n, H, W, float(self._highPassSigma),
+                int(self.parameters['decon_filter_size']),
+                float(self._deconSigma), int(self._deconIterations),
+                out.data_ptr(), None if hist is None else hist.data_ptr(),
+                int(hist_group), batch, ws.data_ptr(), ws.numel(),
+                _stream_ptr(dev)))
+        return out.reshape(shape), hist

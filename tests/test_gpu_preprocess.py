@@ -1,0 +1,200 @@
+"""GPU parity of the preprocess stage (csrc/preprocess.hip through the C-ABI)
+against oracle/preprocess_oracle.py and the reference-made goldens.
+
+Bars: the uint16 high-pass filter is bit-exact.  The float64 deconvolution is
+bit-exact while the acceleration parameter is still 0 (the first two
+iterations: same operations in the same order); from the third iteration on
+lambda = sum(T1 T2) / sum(T2 T2) is reduced in a fixed tile order instead of
+numpy's pairwise order, so float64 results agree to 1e-9 relative and the
+uint16 hand-over may differ by one count on <= 1e-5 of the pixels."""
+import numpy as np
+import pytest
+
+from test_preprocess_oracle import PP_NAMES, load_pp
+import preprocess_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def camera(shape, n_spots, seed, offset=2000):
+    rng = np.random.default_rng(seed)
+    h, w = shape
+    img = offset + rng.poisson(100, size=shape).astype(np.float64)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n_spots):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        img += rng.uniform(500, 6000) * np.exp(
+            -((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * 1.4 ** 2))
+    return np.clip(np.rint(img), 0, 65535).astype(np.uint16)
+
+
+def check_f64(got, want, rtol=1e-9):
+    scale = np.maximum(np.abs(want), 1.0)
+    err = np.abs(got - want) / scale
+    assert err.max() <= rtol, 'max relative error {:.3g}'.format(err.max())
+
+
+def check_u16(got, want, frac=1e-5):
+    diff = got.astype(np.int64) - want.astype(np.int64)
+    bad = np.count_nonzero(diff)
+    assert bad <= max(1, frac * got.size) and (bad == 0 or np.abs(diff).max() == 1), \
+        '{} of {} pixels differ, max |diff| {}'.format(bad, got.size, np.abs(diff).max())
+
+
+@pytest.mark.parametrize('name', PP_NAMES)
+def test_high_pass_golden(gpu_device, name):
+    from merlin_amd import preprocess as pp
+    g = load_pp(name)
+    s = g['p']['hp_sigma']
+    hp = pp.high_pass_filter(g['image'], po.filter_size_for_sigma(s), s)
+    assert hp.dtype == np.uint16 and np.array_equal(hp, g['highpass'])
+
+
+@pytest.mark.parametrize('shape,window,sigma', [
+    ((1, 1), 13, 3.0), ((5, 3), 13, 3.0), ((33, 65), 13, 3.0), ((70, 130), 5, 1.0),
+    ((64, 64), 17, 4.0), ((40, 200), 1, 0.0), ((97, 31), 9, 3.0)])
+def test_high_pass_shapes(gpu_device, shape, window, sigma):
+    from merlin_amd import preprocess as pp
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = rng.integers(0, 65536, size=shape, dtype=np.uint16)
+    assert np.array_equal(pp.high_pass_filter(img, window, sigma),
+                          po.high_pass_filter(img, window, sigma))
+
+
+def test_high_pass_batch_of_images(gpu_device):
+    import torch
+    from merlin_amd import preprocess as pp
+    stack = np.stack([camera((50, 90), 10, s) for s in range(6)]).reshape(3, 2, 50, 90)
+    got = pp.high_pass_filter_device(torch.from_numpy(stack).to(gpu_device), 13, 3).cpu().numpy()
+    for b in range(3):
+        for z in range(2):
+            assert np.array_equal(got[b, z], po.high_pass_filter(stack[b, z], 13, 3))
+
+
+@pytest.mark.parametrize('name', PP_NAMES)
+def test_lucy_richardson_golden(gpu_device, name):
+    import torch
+    from merlin_amd import preprocess as pp
+    g = load_pp(name)
+    p = g['p']
+    hp = torch.from_numpy(g['highpass']).to(gpu_device)
+    dec, lam = pp.deconvolve_lucyrichardson_device(
+        hp, p['decon_size'], p['decon_sigma'], p['iterations'], return_lambdas=True)
+    trace = []
+    want = po.deconvolve_lucyrichardson(g['highpass'].astype(np.float64), p['decon_size'],
+                                        p['decon_sigma'], p['iterations'], trace)
+    assert np.array_equal(want, g['deconvolved'])
+    np.testing.assert_allclose(lam.cpu().numpy()[0], np.array(trace), rtol=1e-11, atol=1e-14)
+    check_f64(dec.cpu().numpy(), g['deconvolved'])
+    out16 = pp.deconvolve_lucyrichardson_device(
+        hp, p['decon_size'], p['decon_sigma'], p['iterations'], out_dtype=torch.uint16)
+    check_u16(out16.cpu().numpy(), g['output'])
+    # the numpy drop-in takes the reference's float64 image
+    dec2 = pp.deconvolve_lucyrichardson(g['highpass'].astype(np.float64), p['decon_size'],
+                                        p['decon_sigma'], p['iterations'])
+    assert np.array_equal(dec2, dec.cpu().numpy())
+
+
+@pytest.mark.parametrize('iterations', [0, 1, 2])
+@pytest.mark.parametrize('window,sigma', [(9, 2.0), (5, 1.0), (13, 3.0), (1, 0.5), (3, 0.8)])
+def test_unaccelerated_iterations_bit_exact(gpu_device, iterations, window, sigma):
+    from merlin_amd import preprocess as pp
+    img = po.high_pass_filter(camera((75, 141), 30, 5), 13, 3).astype(np.float64)
+    got = pp.deconvolve_lucyrichardson(img, window, sigma, iterations)
+    want = po.deconvolve_lucyrichardson(img, window, sigma, iterations)
+    assert np.array_equal(got, want)
+
+
+def test_float_input_with_negatives_and_zeros(gpu_device):
+    from merlin_amd import preprocess as pp
+    rng = np.random.default_rng(3)
+    img = rng.normal(50, 40, size=(64, 100))
+    img[10:20, 10:20] = 0.0
+    got = pp.deconvolve_lucyrichardson(img, 9, 2, 2)
+    assert np.array_equal(got, po.deconvolve_lucyrichardson(img, 9, 2, 2))
+    check_f64(pp.deconvolve_lucyrichardson(img, 9, 2, 8),
+              po.deconvolve_lucyrichardson(img, 9, 2, 8))
+    zero = np.zeros((40, 70))
+    assert np.array_equal(pp.deconvolve_lucyrichardson(zero, 9, 2, 20), zero)
+
+
+@pytest.mark.parametrize('name', PP_NAMES)
+def test_preprocess_image_golden(gpu_device, name):
+    from merlin_amd import preprocess as pp
+    g = load_pp(name)
+    p = g['p']
+    task = pp.DeconvolutionPreprocess(dict(
+        highpass_sigma=p['hp_sigma'], decon_sigma=p['decon_sigma'],
+        decon_filter_size=p['decon_size'], decon_iterations=p['iterations']))
+    out = task._preprocess_image(g['image'])
+    assert out.dtype == np.uint16
+    check_u16(out, g['output'])
+    hp = task._high_pass_filter(g['image'])
+    assert hp.dtype == np.float64 and np.array_equal(hp, g['highpass'].astype(np.float64))
+
+
+def test_stack_histogram_batches_and_determinism(gpu_device):
+    import torch
+    from merlin_amd import preprocess as pp
+    B, Z, H, W = 3, 2, 70, 100
+    stack = np.stack([camera((H, W), 15, 10 + s) for s in range(B * Z)]).reshape(B, Z, H, W)
+    stack[0, 0, :4, :4] = 65535                 # saturated corner: wraps past 65535
+    dev_stack = torch.from_numpy(stack).to(gpu_device)
+    outs = []
+    for batch in (1, 4, 6, None):
+        out, hist = pp.DeconvolutionPreprocess(batch=batch).preprocess_device(dev_stack)
+        out, hist = out.cpu().numpy(), hist.cpu().numpy()
+        assert out.shape == stack.shape and hist.shape == (B, 65534)
+        for b in range(B):      # histogram of the GPU's own output, exactly
+            assert np.array_equal(hist[b], po.pixel_histogram(out[b]).astype(np.int64))
+        outs.append(out)
+    for o in outs[1:]:          # batching and repetition change nothing
+        assert np.array_equal(o, outs[0])
+    for b in range(B):
+        for z in range(Z):
+            check_u16(outs[0][b, z], po.preprocess_image(stack[b, z]))
+
+
+def test_errors(gpu_device):
+    import torch
+    from merlin_amd import preprocess as pp
+    img = np.zeros((32, 32))
+    with pytest.raises(NotImplementedError):
+        pp.deconvolve_lucyrichardson(img, 8, 2, 3)           # ndimage branch
+    with pytest.raises(NotImplementedError):
+        pp.deconvolve_lucyrichardson(img, 15, 2, 3)
+    with pytest.raises(NotImplementedError):
+        pp.high_pass_filter(img.astype(np.uint16), 19, 4.5)
+    with pytest.raises(NotImplementedError):
+        pp.high_pass_filter(img.astype(np.float32), 13, 3)
+    with pytest.raises(ValueError):
+        pp.deconvolve_lucyrichardson(img, 9, 2, -1)
+    with pytest.raises(ValueError):
+        pp.deconvolve_lucyrichardson_device(
+            torch.zeros((2, 8, 8), dtype=torch.uint16, device=gpu_device), 9, 2, 2,
+            out_dtype=torch.uint16,
+            histogram=torch.zeros((1, 10), dtype=torch.int64, device=gpu_device))
+
+
+def test_full_size_image(gpu_device):
+    """2048 x 2048 (BASELINE config sizes): one image against the oracle, and
+    independence from the images it is batched with."""
+    import torch
+    from merlin_amd import preprocess as pp
+    rng = np.random.default_rng(77)
+    H = W = 2048
+    img = (2000 + rng.poisson(100, size=(H, W))).astype(np.float64)
+    ys, xs = rng.integers(8, H - 8, 4000), rng.integers(8, W - 8, 4000)
+    yy, xx = np.mgrid[-6:7, -6:7]
+    psf = np.exp(-(yy ** 2 + xx ** 2) / (2 * 1.4 ** 2))
+    for y, x, a in zip(ys, xs, rng.uniform(500, 6000, 4000)):
+        img[y - 6:y + 7, x - 6:x + 7] += a * psf
+    img = np.clip(np.rint(img), 0, 65535).astype(np.uint16)
+    want = po.preprocess_image(img)
+    pair = torch.from_numpy(np.stack([img, img[::-1].copy()])).to(gpu_device)
+    out, hist = pp.DeconvolutionPreprocess(batch=2).preprocess_device(pair, hist_group=1)
+    out = out.cpu().numpy()
+    check_u16(out[0], want)
+    assert np.array_equal(hist[0].cpu().numpy(), po.pixel_histogram(out[0]).astype(np.int64))
+    alone, _ = pp.DeconvolutionPreprocess(batch=1).preprocess_device(pair[:1], histogram=False)
+    assert np.array_equal(alone.cpu().numpy()[0], out[0])
