@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 passes over the preprocess stage: kernel stats, then PMC passes.
+set -o pipefail
+tag=${1:-x}; batch=${2:-1}
+out=gpurun_out/prof_pp_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- \
+    python3 dev/run_pp.py 4 $batch > $out/kt.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES \
+    --kernel-include-regex lr_stream --output-format csv -d $out/sq -o sq -- python3 dev/run_pp.py 1 1 > $out/sq.log 2>&1 || exit 2
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex lr_stream --output-format csv \
+    -d $out/fetch -o fetch -- python3 dev/run_pp.py 2 $batch > $out/fetch.log 2>&1 || exit 3
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex lr_stream --output-format csv \
+    -d $out/write -o write -- python3 dev/run_pp.py 2 $batch > $out/write.log 2>&1 || exit 4
+find $out -name '*.csv' | head -20

@@ -6,20 +6,12 @@
 // merlin/analysis/preprocess.py:114-140 (_preprocess_image + pixel histogram).
 //
 // The deconvolution is float64 like the reference and bound by memory traffic:
-// per iteration and pixel it reads J1, J2 (twice), the previous difference T1
-// and the blurred ratio, and writes the ratio, the new J1 and T1 (82 B/px with
-// a uint16 observed image).  Two launches per iteration:
-//
-//   lr_reblur : Y = max(J1 + lambda (J1 - J2), 0) is rebuilt on the fly for a
-//               64 x 32 tile plus halo, blurred through LDS (row pass left to
-//               right, column pass centre-out: OpenCV's RowFilter /
-//               SymmColumnFilter order) and turned into the ratio
-//               wI / max(reblurred, eps) + eps.
-//   lr_update : blurs the ratio the same way, J1' = Y * blurred, T1' = J1' - Y,
-//               and reduces sum(T1' T1) and sum(T1 T1) for the next lambda in a
-//               fixed order: per thread, per wave, per tile, then the LAST
-//               tile of the image to finish adds the tile partials in tile
-//               order (no float atomics, run-to-run identical).
+// per iteration and pixel it reads J1, J2 (twice), the observed image, the
+// previous difference T1 and the ratio, and writes the ratio, the new J1 and T1
+// (74 B/px with a uint16 observed image).  Two launches per iteration
+// (lr_stream_kernel, UPDATE = false / true), each a grid of single-wave
+// workgroups that stream 64-column strips through a register ring; the sums
+// behind the acceleration parameter are reduced in a fixed order.
 //
 // Images are processed a few at a time (`batch`) so that one batch's working
 // set (34 B/px: 143 MB for a 2048 x 2048 image) stays inside the 256 MiB
@@ -31,12 +23,17 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 
 namespace {
 
 constexpr int TW = 64;          // tile width = wave width
+#ifndef MF_LR_SEG
+#define MF_LR_SEG 32
+#endif
+constexpr int SEG = MF_LR_SEG;  // rows of one deconvolution strip segment
 constexpr int TH = 32;          // tile height: 4 waves x 8 rows
 constexpr int NT = 256;
 constexpr int ROWS_PER_WAVE = TH / 4;
@@ -73,50 +70,6 @@ __device__ __forceinline__ double make_y(double j1, double j2, double lam)
     return y < 0.0 ? 0.0 : y;      // np.clip keeps NaN
 }
 
-// Separable blur of one tile.  `src(gy, gx)` yields the (border-replicated)
-// input; the result of this thread's ROWS_PER_WAVE vertically adjacent pixels
-// (column x0 + lane, rows y0 + wave*8 ..) is left in out[].
-template <int R, typename Src>
-__device__ __forceinline__ void blur_tile(const Taps &tp, int x0, int y0, int H, int W,
-                                          double *sIn, double *sH, Src src,
-                                          double (&out)[ROWS_PER_WAVE])
-{
-    constexpr int IW = TW + 2 * R, IH = TH + 2 * R;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < IW * IH; e += NT) {
-        const int r = e / IW, c = e - r * IW;
-        sIn[e] = src(clampi(y0 - R + r, 0, H - 1), clampi(x0 - R + c, 0, W - 1));
-    }
-    __syncthreads();
-    // row pass (OpenCV RowFilter): s = k[0] S[0]; s += k[j] S[j]
-    for (int r = wave; r < IH; r += 4) {
-        const double *row = sIn + r * IW + lane;
-        double s = tp.k[0] * row[0];
-#pragma unroll
-        for (int j = 1; j <= 2 * R; ++j) s = s + tp.k[j] * row[j];
-        sH[r * TW + lane] = s;
-    }
-    __syncthreads();
-    // column pass (OpenCV SymmColumnFilter): centre, then pairs outwards
-    double col[ROWS_PER_WAVE + 2 * R];
-#pragma unroll
-    for (int j = 0; j < ROWS_PER_WAVE + 2 * R; ++j)
-        col[j] = sH[(wave * ROWS_PER_WAVE + j) * TW + lane];
-#pragma unroll
-    for (int o = 0; o < ROWS_PER_WAVE; ++o) {
-        double s = tp.k[R] * col[o + R];
-#pragma unroll
-        for (int j = 1; j <= R; ++j) s = s + tp.k[R + j] * (col[o + R + j] + col[o + R - j]);
-        out[o] = s;
-    }
-}
-
-template <int R>
-constexpr size_t blur_lds_bytes()
-{
-    return ((size_t)(TW + 2 * R) * (TH + 2 * R) + (size_t)TW * (TH + 2 * R)) * sizeof(double);
-}
-
 struct LrArgs {
     const void *wi;          // observed image(s), u16 or f64 [n][HW]
     const double *j1, *j2;   // [n][HW]
@@ -134,49 +87,24 @@ struct LrArgs {
     Taps tp;
 };
 
-template <int R, typename WT>
-__global__ void __launch_bounds__(NT) lr_reblur_kernel(const LrArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *sIn = reinterpret_cast<double *>(smem);
-    double *sH = sIn + (TW + 2 * R) * (TH + 2 * R);
-    const int t = xcd_tile(a.tiles);
-    if (t < 0) return;
-    const int img = blockIdx.y;
-    const int64_t base = (int64_t)img * a.H * a.W;
-    const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * TH;
-    const double lam = a.lam[img];
-    const double *j1 = a.j1 + base, *j2 = a.j2 + base;
-    const int W = a.W;
-    double out[ROWS_PER_WAVE];
-    blur_tile<R>(a.tp, x0, y0, a.H, W, sIn, sH,
-                 [&](int gy, int gx) {
-                     const int64_t p = (int64_t)gy * W + gx;
-                     return make_y(j1[p], j2[p], lam);
-                 },
-                 out);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gx = x0 + lane;
-    const WT *wi = reinterpret_cast<const WT *>(a.wi) + base;
-    if (gx < W) {
-#pragma unroll
-        for (int o = 0; o < ROWS_PER_WAVE; ++o) {
-            const int gy = y0 + wave * ROWS_PER_WAVE + o;
-            if (gy < a.H) {
-                const int64_t p = (int64_t)gy * W + gx;
-                double rb = out[o];
-                rb = rb < EPS ? EPS : rb;                       // np.clip(reblurred, eps, None)
-                a.ratio[base + p] = load_wi(wi, p) / rb + EPS;  // cv2.divide; imR += eps
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ double atomic_load_f64(const double *p)
 {
     const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return __longlong_as_double((long long)v);
+}
+
+__device__ __forceinline__ void atomic_store_f64(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// compile-time ordering of LDS accesses among the lanes of one wave
+__device__ __forceinline__ void lds_wave_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -186,83 +114,175 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;       // lane 0 holds the total
 }
 
-template <int R>
-__global__ void __launch_bounds__(NT) lr_update_kernel(const LrArgs a)
+// One wave streams a 64-column strip of SEG rows from top to bottom.  Per input
+// row: the wave's 64 + 2R values go through one LDS row for the row pass
+// (OpenCV RowFilter: s = k[0] S[0]; s += k[j] S[j], left to right), the row
+// sums of the last 2R + 1 rows live in a register ring, and the column pass
+// (SymmColumnFilter: centre, then k[R+j] (S[+j] + S[-j]) outwards) finishes
+// output row r - R.  No workgroup barrier (a workgroup is one wave), the next
+// row's loads are in flight while this one is filtered, and up to eight such
+// waves per SIMD hide what is left of the latency.
+//
+// UPDATE = false (lr_reblur): source Y = max(J1 + lambda (J1 - J2), 0) rebuilt on
+//   the fly; output ratio = wI / max(blur, eps) + eps       (deconvolve.py:112-122)
+// UPDATE = true  (lr_update): source = ratio; J1' = Y * blur, T1' = J1' - Y, and
+//   the tile's sums of T1' T1 and T1 T1; the LAST tile of the image to finish
+//   adds the tile partials in tile order and publishes the next lambda
+//   (no float atomics: identical from run to run)           (deconvolve.py:107-132)
+template <int R, int SEGT, int P, typename WT, bool UPDATE>
+__global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *sIn = reinterpret_cast<double *>(smem);
-    double *sH = sIn + (TW + 2 * R) * (TH + 2 * R);
-    __shared__ double red[2][NT / 64];
-    __shared__ int is_last;
+    __shared__ double srow[TW + 2 * R + 2];
     const int t = xcd_tile(a.tiles);
     if (t < 0) return;
     const int img = blockIdx.y;
-    const int64_t base = (int64_t)img * a.H * a.W;
-    const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * TH;
+    const int lane = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int64_t base = (int64_t)img * H * W;
+    const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * SEGT;
+    const int rows_out = min(SEGT, H - y0);
     const double lam = a.lam[img];
+    const double *j1 = a.j1 + base, *j2 = a.j2 + base;
     const double *ratio = a.ratio + base;
-    const int W = a.W;
-    double out[ROWS_PER_WAVE];
-    blur_tile<R>(a.tp, x0, y0, a.H, W, sIn, sH,
-                 [&](int gy, int gx) { return ratio[(int64_t)gy * W + gx]; }, out);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const WT *wi = reinterpret_cast<const WT *>(a.wi) + base;
+    const double *t1 = a.t1 + base;
+    // source columns: lane L holds x0 - R + L, lanes < 2R also x0 - R + 64 + L
+    const int cm = clampi(x0 - R + lane, 0, W - 1);
+    const int ch = clampi(x0 - R + TW + lane, 0, W - 1);
+    const bool has_halo = lane < 2 * R;
     const int gx = x0 + lane;
-    double s_ab = 0.0, s_bb = 0.0;
-    if (gx < W) {
+    const int cg = min(gx, W - 1);
+
+    // P source rows and P output rows' operands in flight, in fixed registers
+    // (the row loop is unrolled P times so that no load target is ever moved)
+    double m0[P], m1[P], h0[P], h1[P];
+    double e0[P], e1[P], e2[P];
+    WT w0[P];            // raw observed value: converted where it is used, not where it lands
 #pragma unroll
-        for (int o = 0; o < ROWS_PER_WAVE; ++o) {
-            const int gy = y0 + wave * ROWS_PER_WAVE + o;
-            if (gy < a.H) {
-                const int64_t p = base + (int64_t)gy * W + gx;
-                const double y = make_y(a.j1[p], a.j2[p], lam);
-                const double jn = y * out[o];            // np.multiply(Y, imR, out=J1)
-                const double tn = jn - y;                // np.subtract(J1, Y, out=T1)
-                const double to = a.t1[p];
-                a.jnew[p] = jn;
-                a.t1[p] = tn;
-                s_ab = s_ab + tn * to;                   // cv2.multiply(T1, T2) summed
-                s_bb = s_bb + to * to;
+    for (int u = 0; u < P; ++u) {
+        m0[u] = m1[u] = h0[u] = h1[u] = e0[u] = e1[u] = e2[u] = 0.0;
+        w0[u] = (WT)0;
+    }
+    auto fetch = [&](int u, int r) {
+        const int64_t row = (int64_t)clampi(y0 + r, 0, H - 1) * W;
+        if constexpr (UPDATE) {
+            m0[u] = ratio[row + cm];
+            if (has_halo) h0[u] = ratio[row + ch];
+        } else {
+            m0[u] = j1[row + cm];
+            m1[u] = j2[row + cm];
+            if (has_halo) { h0[u] = j1[row + ch]; h1[u] = j2[row + ch]; }
+        }
+    };
+    auto fetch_epilogue = [&](int u, int ro) {
+        const int64_t p = (int64_t)clampi(y0 + ro, 0, H - 1) * W + cg;
+        if constexpr (UPDATE) { e0[u] = j1[p]; e1[u] = j2[p]; e2[u] = t1[p]; }
+        else w0[u] = wi[p];
+    };
+
+    double ring[2 * R + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) ring[j] = 0.0;
+    double s_ab = 0.0, s_bb = 0.0;
+
+    // Straight-line software pipeline: every fetch is unconditional (row
+    // indexes clamp, so rows past the strip only cost a wasted load) and the
+    // trip count is padded to a multiple of P, so that no load target is copied
+    // or waited for before its row is consumed.
+    const int r_end = rows_out + R;
+#pragma unroll
+    for (int u = 0; u < P; ++u) { fetch(u, -R + u); fetch_epilogue(u, -2 * R + u); }
+    for (int rb = -R; rb < r_end; rb += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int r = rb + u;
+            double vm, vh;
+            if constexpr (UPDATE) { vm = m0[u]; vh = h0[u]; }
+            else { vm = make_y(m0[u], m1[u], lam); vh = make_y(h0[u], h1[u], lam); }
+            const double c0 = e0[u], c1 = e1[u], c2 = e2[u];
+            const WT cw = w0[u];
+            fetch(u, r + P);
+            fetch_epilogue(u, r + P - R);
+            // one wave per workgroup: LDS operations of a wave execute in
+            // order, so the row only needs the compiler to keep them in order
+            // (a __syncthreads() would also wait for every global load in flight)
+            lds_wave_order();
+            srow[lane] = vm;
+            if (has_halo) srow[TW + lane] = vh;
+            lds_wave_order();
+            double s = a.tp.k[0] * srow[lane];
+#pragma unroll
+            for (int j = 1; j <= 2 * R; ++j) s = s + a.tp.k[j] * srow[lane + j];
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) ring[j] = ring[j + 1];
+            ring[2 * R] = s;
+            const int ro = r - R;
+            double o = a.tp.k[R] * ring[R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) o = o + a.tp.k[R + j] * (ring[R + j] + ring[R - j]);
+            const bool ok = ro >= 0 && ro < rows_out && gx < W;
+            const int64_t p = base + (int64_t)(y0 + ro) * W + gx;
+            if constexpr (UPDATE) {
+                const double y = make_y(c0, c1, lam);
+                const double jn = y * o;             // np.multiply(Y, imR, out=J1)
+                const double tn = jn - y;            // np.subtract(J1, Y, out=T1)
+                if (ok) {
+                    a.jnew[p] = jn;
+                    a.t1[p] = tn;
+                }
+                s_ab = s_ab + (ok ? tn * c2 : 0.0);  // cv2.multiply(T1, T2) summed
+                s_bb = s_bb + (ok ? c2 * c2 : 0.0);
+            } else {
+                const double rbl = o < EPS ? EPS : o;              // np.clip(reblurred, eps, None)
+                if (ok) a.ratio[p] = (double)cw / rbl + EPS;       // cv2.divide; imR += eps
             }
         }
     }
-    s_ab = wave_sum(s_ab);
-    s_bb = wave_sum(s_bb);
-    if (lane == 0) { red[0][wave] = s_ab; red[1][wave] = s_bb; }
-    __syncthreads();
-    if (tid == 0) {
-        double *pp = a.partials + ((int64_t)img * a.tiles + t) * 2;
-        pp[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        pp[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        __threadfence();                                  // partials before the ticket
-        const unsigned ticket = atomicAdd(a.counters + img, 1u);
-        is_last = ticket == (unsigned)a.tiles - 1u;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    // last tile of this image: add the tile partials in tile order
-    __threadfence();
-    const double *pp = a.partials + (int64_t)img * a.tiles * 2;
-    double ab = 0.0, bb = 0.0;
-    for (int i = tid; i < a.tiles; i += NT) {
-        ab = ab + atomic_load_f64(pp + 2 * i);
-        bb = bb + atomic_load_f64(pp + 2 * i + 1);
-    }
-    ab = wave_sum(ab);
-    bb = wave_sum(bb);
-    __syncthreads();
-    if (lane == 0) { red[0][wave] = ab; red[1][wave] = bb; }
-    __syncthreads();
-    if (tid == 0) {
-        ab = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        bb = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        double l = ab / (bb + EPS);                       // deconvolve.py:110
-        l = 1.0 < l ? 1.0 : l;                            // min(l, 1)
-        l = 0.0 > l ? 0.0 : l;                            // max(., 0)
-        // the reference only starts accelerating at its third iteration
-        if (a.iter + 1 <= 1) l = 0.0;
-        a.lam_next[img] = l;
-        if (a.lam_trace) a.lam_trace[(int64_t)img * a.trace_stride + a.iter + 1] = l;
-        a.counters[img] = 0u;
+    if constexpr (UPDATE) {
+        // Tile partials cross to the reducing wave as 8-byte agent-scope
+        // (sc1) stores and loads with the storing wave's vmcnt(0) before its
+        // ticket: no L2 write-back / invalidate per tile.
+        s_ab = wave_sum(s_ab);
+        s_bb = wave_sum(s_bb);
+        unsigned ticket = 0;
+        if (lane == 0) {
+            double *pp = a.partials + ((int64_t)img * a.tiles + t) * 2;
+            atomic_store_f64(pp, s_ab);
+            atomic_store_f64(pp + 1, s_bb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket = atomicAdd(a.counters + img, 1u);
+        }
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket != (unsigned)a.tiles - 1u) return;
+        // last tile of this image: lane i adds tiles i, i + 64, ... in order
+        const double *pp = a.partials + (int64_t)img * a.tiles * 2;
+        double ab = 0.0, bb = 0.0;
+        constexpr int U = 8;
+        for (int i0 = lane; i0 < a.tiles; i0 += 64 * U) {
+            double va[U], vb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + 64 * u;
+                va[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i) : 0.0;
+                vb[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i + 1) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + 64 * u < a.tiles) { ab = ab + va[u]; bb = bb + vb[u]; }
+            }
+        }
+        ab = wave_sum(ab);
+        bb = wave_sum(bb);
+        if (lane == 0) {
+            double l = ab / (bb + EPS);                   // deconvolve.py:110
+            l = 1.0 < l ? 1.0 : l;                        // min(l, 1)
+            l = 0.0 > l ? 0.0 : l;                        // max(., 0)
+            // the reference only starts accelerating at its third iteration
+            if (a.iter + 1 <= 1) l = 0.0;
+            a.lam_next[img] = l;
+            if (a.lam_trace) a.lam_trace[(int64_t)img * a.trace_stride + a.iter + 1] = l;
+            a.counters[img] = 0u;
+        }
     }
 }
 
@@ -427,7 +447,7 @@ struct Workspace {
 void layout_workspace(int batch, int H, int W, unsigned char *base, Workspace &ws)
 {
     const size_t hw = (size_t)H * W;
-    const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + SEG - 1) / SEG);
     size_t off = 0;
     auto take = [&](size_t bytes) { unsigned char *p = base + off; off += align256(bytes); return p; };
     ws.ja = reinterpret_cast<double *>(take(batch * hw * 8));
@@ -441,25 +461,36 @@ void layout_workspace(int batch, int H, int W, unsigned char *base, Workspace &w
     ws.total = off;
 }
 
+#ifndef MF_LR_PREFETCH
+#define MF_LR_PREFETCH 4
+#endif
+
+template <int R, int P, typename WT>
+int launch_iteration_p(const LrArgs &a, int n, hipStream_t s)
+{
+    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
+    hipLaunchKernelGGL((lr_stream_kernel<R, SEG, P, WT, false>), grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL((lr_stream_kernel<R, SEG, P, WT, true>), grid, dim3(64), 0, s, a);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
 template <int R, typename WT>
 int launch_iteration(const LrArgs &a, int n, hipStream_t s)
 {
-    const size_t lds = blur_lds_bytes<R>();
-    auto ka = lr_reblur_kernel<R, WT>;
-    auto kb = lr_update_kernel<R>;
-    static bool attr_done = false;       // per instantiation; idempotent
-    if (!attr_done && lds > 48 * 1024) {
-        MF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ka),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kb),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+#ifdef MF_LR_TUNE      // development build: prefetch depth from the environment
+    if (R == 4) {
+        static const int p = std::getenv("MF_LR_P") ? std::atoi(std::getenv("MF_LR_P")) : MF_LR_PREFETCH;
+        switch (p) {
+        case 1: return launch_iteration_p<R, 1, WT>(a, n, s);
+        case 2: return launch_iteration_p<R, 2, WT>(a, n, s);
+        case 3: return launch_iteration_p<R, 3, WT>(a, n, s);
+        case 6: return launch_iteration_p<R, 6, WT>(a, n, s);
+        case 8: return launch_iteration_p<R, 8, WT>(a, n, s);
+        }
     }
-    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
-    hipLaunchKernelGGL(ka, grid, dim3(NT), lds, s, a);
-    hipLaunchKernelGGL(kb, grid, dim3(NT), lds, s, a);
-    MF_HIP_CHECK(hipGetLastError());
-    return MF_OK;
+#endif
+    return launch_iteration_p<R, MF_LR_PREFETCH, WT>(a, n, s);
 }
 
 template <typename WT>
@@ -529,7 +560,7 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
     a.counters = ws.counters;
     a.H = H; a.W = W;
     a.tiles_x = (W + TW - 1) / TW;
-    a.tiles = a.tiles_x * ((H + TH - 1) / TH);
+    a.tiles = a.tiles_x * ((H + SEG - 1) / SEG);
     a.tp = tp;
     a.trace_stride = iterations;
     double *j1 = ws.ja, *j2 = ws.jb;
