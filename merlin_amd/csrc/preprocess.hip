@@ -13,9 +13,11 @@
 // workgroups that stream 64-column strips through a register ring; the sums
 // behind the acceleration parameter are reduced in a fixed order.
 //
-// Images are processed a few at a time (`batch`) so that one batch's working
-// set (34 B/px: 143 MB for a 2048 x 2048 image) stays inside the 256 MiB
-// Infinity Cache from one iteration to the next instead of streaming from HBM.
+// Images are processed `batch` at a time (one launch covers the batch; the
+// working set is 34 B/px per image).  Measured on MI355X the batch size hardly
+// matters (1.43 ms per 2048 x 2048 frame at batch 2, inside the Infinity Cache,
+// and at batch 14, far outside it): the kernels run at the mixed read/write
+// rate of the memory system either way.
 //
 // Built with -ffp-contract=off: every product and sum below rounds on its own,
 // as the non-FMA scalar path of OpenCV and numpy do.
@@ -31,7 +33,7 @@ namespace {
 
 constexpr int TW = 64;          // tile width = wave width
 #ifndef MF_LR_SEG
-#define MF_LR_SEG 32
+#define MF_LR_SEG 64
 #endif
 constexpr int SEG = MF_LR_SEG;  // rows of one deconvolution strip segment
 constexpr int TH = 32;          // tile height: 4 waves x 8 rows
@@ -163,8 +165,10 @@ __global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
         m0[u] = m1[u] = h0[u] = h1[u] = e0[u] = e1[u] = e2[u] = 0.0;
         w0[u] = (WT)0;
     }
+    // rows past either end of the strip (pipeline warm-up and drain) are
+    // redirected to rows the wave reads anyway: an L1/L2 hit, no fabric traffic
     auto fetch = [&](int u, int r) {
-        const int64_t row = (int64_t)clampi(y0 + r, 0, H - 1) * W;
+        const int64_t row = (int64_t)clampi(y0 + min(r, rows_out + R - 1), 0, H - 1) * W;
         if constexpr (UPDATE) {
             m0[u] = ratio[row + cm];
             if (has_halo) h0[u] = ratio[row + ch];
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
         }
     };
     auto fetch_epilogue = [&](int u, int ro) {
-        const int64_t p = (int64_t)clampi(y0 + ro, 0, H - 1) * W + cg;
+        const int64_t p = (int64_t)(y0 + clampi(ro, 0, rows_out - 1)) * W + cg;
         if constexpr (UPDATE) { e0[u] = j1[p]; e1[u] = j2[p]; e2[u] = t1[p]; }
         else w0[u] = wi[p];
     };
@@ -336,6 +340,7 @@ __global__ void __launch_bounds__(NT) lr_finalize_kernel(const double *j, void *
     unsigned long long *row = hist ? hist + (int64_t)((img0 + img) / hist_group) * HIST_BINS : nullptr;
     const int64_t per = (hw + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = min(hw, lo + per);
+    unsigned zeros = 0;      // most deconvolved pixels are 0: one LDS add per thread, not per pixel
     for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
         const double v = src[i];
         if (out_f64) {
@@ -344,12 +349,14 @@ __global__ void __launch_bounds__(NT) lr_finalize_kernel(const double *j, void *
             const uint16_t u = to_u16(v);
             reinterpret_cast<uint16_t *>(out)[(int64_t)img * hw + i] = u;
             if (hist) {
-                if (u < HIST_LOW) atomicAdd(&low[u], 1u);
+                if (u == 0) ++zeros;
+                else if (u < HIST_LOW) atomicAdd(&low[u], 1u);
                 else if (u < 65535) atomicAdd(row + min((int)u, HIST_BINS - 1), 1ull);
             }
         }
     }
     if (hist) {
+        if (zeros) atomicAdd(&low[0], zeros);
         __syncthreads();
         for (int i = threadIdx.x; i < HIST_LOW; i += NT)
             if (low[i]) atomicAdd(row + i, (unsigned long long)low[i]);
@@ -366,14 +373,14 @@ struct HpArgs {
     Taps tp;
 };
 
+template <int R>
 __global__ void __launch_bounds__(NT) high_pass_kernel(const HpArgs a)
 {
-    constexpr int MR = MF_PP_MAX_RADIUS;
-    __shared__ uint16_t sIn[(TH + 2 * MR) * (TW + 2 * MR)];
-    __shared__ uint32_t sH[(TH + 2 * MR) * TW];
+    constexpr int IW = TW + 2 * R, IH = TH + 2 * R;
+    __shared__ uint16_t sIn[IH * IW];
+    __shared__ uint32_t sH[IH * TW];
     const int t = xcd_tile(a.tiles);
     if (t < 0) return;
-    const int R = a.R, IW = TW + 2 * R, IH = TH + 2 * R;
     const int64_t base = (int64_t)blockIdx.y * a.H * a.W;
     const uint16_t *in = a.in + base;
     const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * TH;
@@ -384,8 +391,9 @@ __global__ void __launch_bounds__(NT) high_pass_kernel(const HpArgs a)
     }
     __syncthreads();
     for (int r = wave; r < IH; r += 4) {
-        uint32_t s = 0;
-        for (int j = 0; j <= 2 * R; ++j) s += a.tp.kfix[j] * (uint32_t)sIn[r * IW + lane + j];
+        uint32_t s = 0;      // taps sum to 65536: fits 32 bits; operands < 2^24
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) s += __umul24(a.tp.kfix[j], (uint32_t)sIn[r * IW + lane + j]);
         sH[r * TW + lane] = s;
     }
     __syncthreads();
@@ -394,12 +402,19 @@ __global__ void __launch_bounds__(NT) high_pass_kernel(const HpArgs a)
     for (int o = 0; o < ROWS_PER_WAVE; ++o) {
         const int ly = wave * ROWS_PER_WAVE + o, gy = y0 + ly;
         if (gy >= a.H) break;
-        uint64_t s = 0;
-        for (int j = 0; j <= 2 * R; ++j) s += (uint64_t)a.tp.kfix[j] * sH[(ly + j) * TW + lane];
-        uint64_t lp = (s + (1ull << 31)) >> 32;
+        // V = sum k_j H_j needs 48 bits: split H into 16-bit halves, two exact
+        // u32 sums; (V + 2^31) >> 32 = (hi + (lo >> 16) + 2^15) >> 16
+        uint32_t shi = 0, slo = 0;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) {
+            const uint32_t h = sH[(ly + j) * TW + lane];
+            shi += __umul24(a.tp.kfix[j], h >> 16);
+            slo += __umul24(a.tp.kfix[j], h & 0xffffu);
+        }
+        uint32_t lp = (shi + (slo >> 16) + 0x8000u) >> 16;
         if (lp > 65535) lp = 65535;
         const uint32_t v = sIn[(ly + R) * IW + lane + R];
-        a.out[base + (int64_t)gy * a.W + gx] = lp > v ? (uint16_t)0 : (uint16_t)(v - (uint32_t)lp);
+        a.out[base + (int64_t)gy * a.W + gx] = lp > v ? (uint16_t)0 : (uint16_t)(v - lp);
     }
 }
 
@@ -531,8 +546,19 @@ int run_high_pass(const uint16_t *in, int n, int H, int W, int ksize, double sig
         const int nb = n - i0 < 65535 ? n - i0 : 65535;
         h.in = in + (int64_t)i0 * H * W;
         h.out = out + (int64_t)i0 * H * W;
-        hipLaunchKernelGGL(high_pass_kernel, dim3((unsigned)(((h.tiles + 7) >> 3) << 3), (unsigned)nb),
-                           dim3(NT), 0, s, h);
+        const dim3 grid((unsigned)(((h.tiles + 7) >> 3) << 3), (unsigned)nb);
+        switch (h.R) {
+        case 0: hipLaunchKernelGGL(high_pass_kernel<0>, grid, dim3(NT), 0, s, h); break;
+        case 1: hipLaunchKernelGGL(high_pass_kernel<1>, grid, dim3(NT), 0, s, h); break;
+        case 2: hipLaunchKernelGGL(high_pass_kernel<2>, grid, dim3(NT), 0, s, h); break;
+        case 3: hipLaunchKernelGGL(high_pass_kernel<3>, grid, dim3(NT), 0, s, h); break;
+        case 4: hipLaunchKernelGGL(high_pass_kernel<4>, grid, dim3(NT), 0, s, h); break;
+        case 5: hipLaunchKernelGGL(high_pass_kernel<5>, grid, dim3(NT), 0, s, h); break;
+        case 6: hipLaunchKernelGGL(high_pass_kernel<6>, grid, dim3(NT), 0, s, h); break;
+        case 7: hipLaunchKernelGGL(high_pass_kernel<7>, grid, dim3(NT), 0, s, h); break;
+        case 8: hipLaunchKernelGGL(high_pass_kernel<8>, grid, dim3(NT), 0, s, h); break;
+        default: return mf::fail(MF_EUNSUPPORTED, "high-pass radius %d > %d", h.R, MF_PP_MAX_RADIUS);
+        }
     }
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
