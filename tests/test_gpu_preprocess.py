@@ -198,3 +198,47 @@ def test_full_size_image(gpu_device):
     assert np.array_equal(hist[0].cpu().numpy(), po.pixel_histogram(out[0]).astype(np.int64))
     alone, _ = pp.DeconvolutionPreprocess(batch=1).preprocess_device(pair[:1], histogram=False)
     assert np.array_equal(alone.cpu().numpy()[0], out[0])
+
+
+def test_preprocess_feeds_decode(gpu_device):
+    """Camera frames -> preprocess -> initial scale factors from the pixel
+    histogram (optimize.py:140-155) -> Decode.run_fov, against the same chain
+    through the two oracles."""
+    import warnings
+    import pandas
+    import torch
+    import merfish_oracle as oracle
+    from conftest import ArrayCodebook, frame_to_array, load_golden, synth_stack
+    from merlin_amd import preprocess as pp
+    from merlin_amd.decode import Decode
+    from merlin_amd.optimize import initial_scale_factors
+    cb = load_golden('g2_synth192')['codebook']
+    B, Z, H, W = 16, 2, 96, 128
+    raw = synth_stack(cb, (Z, H, W), 70, seed=8, amp=(800, 4000), psf=1.6)
+    raw = (raw.astype(np.int64) + 1900).clip(0, 65535).astype(np.uint16)     # camera offset
+    stack, hist = pp.DeconvolutionPreprocess().preprocess_device(
+        torch.from_numpy(raw).to(gpu_device))
+    want = np.array([[po.preprocess_image(raw[b, z]) for z in range(Z)] for b in range(B)])
+    got = stack.cpu().numpy()
+    check_u16(got, want)
+    want_hist = np.array([po.pixel_histogram(want[b]) for b in range(B)])
+    if np.array_equal(got, want):
+        assert np.array_equal(hist.cpu().numpy(), want_hist.astype(np.int64))
+    sf = initial_scale_factors(hist.cpu().numpy().astype(np.float64))
+    assert np.array_equal(sf, initial_scale_factors(want_hist))
+    bg = np.zeros(B)
+    params = {'crop_width': 4, 'distance_threshold': 0.5167, 'lowpass_sigma': 1}
+    task = Decode(ArrayCodebook(cb), params, device=gpu_device)
+    bc, vol = task.run_fov(stack, sf, bg, fov=0)
+    dm = oracle.normalized_codebook(cb)
+    frames = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for z in range(Z):
+            di, pm, npt, d = oracle.decode_pixels(got[:, z], dm, sf, bg, 0.5167, 1, 1)
+            assert np.array_equal(vol.decoded[z].cpu().numpy(), di)
+            frames.append(oracle.extract_all_barcodes(cb.shape[0], di, pm, npt, d, 0, 4, z, None, 0))
+    exp = pandas.concat(frames)
+    r, e = frame_to_array(bc, B), frame_to_array(exp, B)
+    assert r.shape == e.shape and len(r) > 10
+    np.testing.assert_allclose(r, e, rtol=1e-6, atol=1e-6)
