@@ -143,3 +143,107 @@ class Decode(object):
             tabled = (decoded[0], pending, decoded[2])
         if tabled is not None:
             yield finish(tabled)
+
+    def run_fovs_from_host(self, hostStacks, scaleFactors, backgrounds,
+                           fovs=None, globalAligner=None, zPositions=None,
+                           preprocess=None, depth=3):
+        """run_fovs for stacks that start in HOST memory (what
+        ``get_processed_image_set`` returns, or -- with ``preprocess`` set to a
+        ``merlin_amd.preprocess.DeconvolutionPreprocess`` -- the warped camera
+        frames it would read): uint16 [B,Z,H,W] numpy arrays or torch CPU
+        tensors.  Uploads run on a copy stream through pinned staging buffers,
+        one FOV ahead of the kernels, so PCIe (0.94 GB per 7-z FOV) overlaps
+        compute.  Yields (barcodes, DecodedVolume) per FOV in order."""
+        dev = self.decoder._dev()
+        up = HostStackUploader(dev, depth=depth)
+        stacks = up.stream(hostStacks)
+        if preprocess is not None:
+            stacks = (preprocess.preprocess_device(s, histogram=False)[0]
+                      for s in stacks)
+        return self.run_fovs(stacks, scaleFactors, backgrounds, fovs=fovs,
+                             globalAligner=globalAligner, zPositions=zPositions)
+
+
+class HostStackUploader(object):
+    """Pinned, multi-buffered host-to-device upload of image stacks on its own
+    HIP stream.
+
+    ``stream(hostStacks)`` yields device tensors in order; the copy of stack
+    k+1 is queued before stack k is handed out, so it crosses PCIe while the
+    consumer's kernels for stack k run.  A device buffer is reused ``depth``
+    stacks later, after the kernels the consumer queued for its previous
+    content have finished (an event recorded when the consumer asks for the
+    next stack): the consumer must have queued every kernel that reads stack k
+    on the current stream before it asks for stack k+1, as run_fovs does.
+    Stacks already in page-locked memory (``torch.Tensor.is_pinned()``) are
+    copied straight from there; anything else goes through a pinned staging
+    buffer first (a multi-threaded host copy)."""
+
+    def __init__(self, device, depth=3):
+        if depth < 2:
+            raise ValueError('depth must be >= 2')
+        self.device = torch.device(device)
+        self.depth = depth
+        with torch.cuda.device(self.device):
+            self.copy_stream = torch.cuda.Stream(self.device)
+        self._dev = [None] * depth
+        self._stage = [None, None]
+        self._stage_free = [None, None]
+
+    def _as_tensor(self, h):
+        if isinstance(h, torch.Tensor):
+            if h.device.type != 'cpu':
+                raise ValueError('host stack expected, got a device tensor')
+            return h.contiguous()
+        return torch.from_numpy(np.ascontiguousarray(h))
+
+    def _issue(self, k, h, consumed):
+        """Queue the upload of host stack h as stack k; returns (device
+        tensor, event that marks the copy complete)."""
+        t = self._as_tensor(h)
+        slot = k % self.depth
+        buf = self._dev[slot]
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+            self._dev[slot] = buf
+        if not t.is_pinned():
+            s = k % 2
+            if self._stage_free[s] is not None:
+                self._stage_free[s].synchronize()      # its last upload has left
+            st = self._stage[s]
+            if st is None or st.shape != t.shape or st.dtype != t.dtype:
+                st = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                self._stage[s] = st
+            st.copy_(t)
+            t = st
+        with torch.cuda.stream(self.copy_stream):
+            if consumed[slot] is not None:
+                self.copy_stream.wait_event(consumed[slot])
+            buf.copy_(t, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        if t is self._stage[k % 2]:
+            self._stage_free[k % 2] = done
+        return buf, done
+
+    def stream(self, hostStacks):
+        consumed = [None] * self.depth
+        it = iter(hostStacks)
+        pending = None
+        k = 0
+        for h in it:
+            nxt = self._issue(k, h, consumed)
+            if pending is not None:
+                buf, done = pending
+                torch.cuda.current_stream(self.device).wait_event(done)
+                yield buf
+                # the consumer has queued its kernels for that stack by now
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                consumed[(k - 1) % self.depth] = ev
+            pending = nxt
+            k += 1
+        if pending is not None:
+            buf, done = pending
+            torch.cuda.current_stream(self.device).wait_event(done)
+            yield buf

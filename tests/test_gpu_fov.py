@@ -181,3 +181,43 @@ def test_optimize_iterations_match_oracle(gpu_device):
         assert set(cur.barcodes) == {0, 1}
         sf, bg, prev = esf, ebg, cur
     assert cur.get_scale_factor_history().shape == (3, 16)
+
+
+def test_run_fovs_from_host_matches_run_fov(gpu_device):
+    """Host-resident stacks through the pinned multi-buffered uploader (more
+    FOVs than device buffers; pageable numpy, pinned and plain CPU tensors)
+    give the tables run_fov gives, with and without the preprocess stage."""
+    import torch
+    from merlin_amd.decode import Decode
+    from merlin_amd.preprocess import DeconvolutionPreprocess
+    cb = load_golden('g2_synth192')['codebook']
+    sf = np.full(16, 350.0)
+    bg = np.zeros(16)
+    task = Decode(ArrayCodebook(cb), {'crop_width': 3}, device=gpu_device)
+    stacks = [synth_stack(cb, (2, 64, 96), 40, seed=30 + i) for i in range(7)]
+    hosts = []
+    for i, s in enumerate(stacks):
+        if i % 3 == 0:
+            hosts.append(s)
+        elif i % 3 == 1:
+            hosts.append(torch.from_numpy(s).pin_memory())
+        else:
+            hosts.append(torch.from_numpy(s))
+    want = [task.run_fov(torch.from_numpy(s).to(gpu_device), sf, bg, fov=10 + i)[0]
+            for i, s in enumerate(stacks)]
+    got = [bc for bc, vol in task.run_fovs_from_host(hosts, sf, bg,
+                                                     fovs=list(range(10, 17)), depth=2)]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert len(w) > 0 and g.equals(w)
+
+    pre = DeconvolutionPreprocess(device=gpu_device)
+    raws = [(s.astype(np.int64) + 1500).clip(0, 65535).astype(np.uint16) for s in stacks[:4]]
+    sf2 = np.full(16, 60.0)
+    want = [task.run_fov(pre.preprocess_device(torch.from_numpy(r).to(gpu_device),
+                                               histogram=False)[0], sf2, bg, fov=i)[0]
+            for i, r in enumerate(raws)]
+    got = [bc for bc, vol in task.run_fovs_from_host(raws, sf2, bg, preprocess=pre)]
+    assert sum(len(w) for w in want) > 0
+    for g, w in zip(got, want):
+        assert g.equals(w)
