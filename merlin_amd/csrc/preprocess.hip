@@ -75,6 +75,8 @@ __device__ __forceinline__ double make_y(double j1, double j2, double lam)
 struct LrArgs {
     const void *wi;          // observed image(s), u16 or f64 [n][HW]
     const double *j1, *j2;   // [n][HW]
+    const double *j3;        // fused kernel: the J before j2 (its buffer receives jnew)
+    const double *lam_prev;  // fused kernel: [n] lambda of the previous iteration
     double *ratio;           // [n][HW]
     double *jnew;            // = j2's buffer
     double *t1;              // [n][HW], updated in place
@@ -290,16 +292,195 @@ __global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
     }
 }
 
+// ---- fused iteration -------------------------------------------------------
+// One launch per iteration.  Within an iteration nothing global separates the
+// two blurs (lambda only links one iteration to the next), so a wave can carry
+// both: it streams a 64-column strip of Y rows, of which the middle 64 - 4R
+// columns are outputs.  Stage 1 (row pass in an LDS row, ring of 2R + 1 row
+// sums, column pass) gives the reblurred row R rows behind the Y stream and from
+// it the ratio row; stage 2 does the same to the ratio rows and finishes output
+// row 2R rows behind: J1' = Y * blur.  The ratio never reaches memory, J1 / J2
+// are fetched once per iteration (plus the strip's halo), and the previous
+// difference T1 = J1 - Y_prev is rebuilt bit-for-bit from the J of two
+// iterations ago (j3, whose buffer then receives J1') instead of being stored:
+// 34 B per pixel and iteration (J1, J2, J3, observed u16 in; J1' out) instead
+// of 74.
+//
+// BORDER_REPLICATE: for the first blur clamped loads replicate Y.  The second
+// blur replicates the RATIO: beyond the left / right image edge its row pass
+// reads the edge column's ratio (clamped LDS index, border strips only), above
+// the top edge the ring is filled with row 0's row sum, below the bottom edge
+// the last row sum is repeated.
+template <int R, int SEGT, int P, typename WT>
+__global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
+{
+    constexpr int OUTW = TW - 4 * R;
+    __shared__ double srow1[TW + 2 * R];
+    __shared__ double srow2[TW + 2 * R];
+    const int t = xcd_tile(a.tiles);
+    if (t < 0) return;
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int64_t base = (int64_t)img * H * W;
+    const int x0 = (t % a.tiles_x) * OUTW, y0 = (t / a.tiles_x) * SEGT;
+    const int rows_out = min(SEGT, H - y0);
+    const double lam = a.lam[img], lam_prev = a.lam_prev[img];
+    const double *j1 = a.j1 + base, *j2 = a.j2 + base, *j3 = a.j3 + base;
+    const WT *wi = reinterpret_cast<const WT *>(a.wi) + base;
+    const int gx = x0 - 2 * R + lane;                 // this lane's column
+    const int cm = clampi(gx, 0, W - 1);
+    const bool out_lane = lane >= 2 * R && lane < TW - 2 * R && gx < W;
+    // the strip reaches past the image's left or right edge (wave-uniform)
+    const bool border_x = x0 - 2 * R < 0 || x0 - 2 * R + TW > W;
+    if (lane < 2 * R) {                               // LDS pads: never written again
+        const int padi = lane < R ? lane : TW + lane;
+        srow1[padi] = 0.0;
+        srow2[padi] = 0.0;
+    }
+
+    // P rows of every stream in flight, in fixed registers: slot u serves loop
+    // rows r = -2R + u (mod P): Y row r, ratio row r - R, output row r - 2R
+    double m0[P], m1[P], e0[P], e1[P], e2[P];
+    WT w0[P];
+    auto fetch = [&](int u, int r) {
+        const int64_t yrow = (int64_t)clampi(y0 + min(r, rows_out + 2 * R - 1), 0, H - 1) * W;
+        m0[u] = j1[yrow + cm];
+        m1[u] = j2[yrow + cm];
+        const int64_t qrow = (int64_t)clampi(y0 + clampi(r - R, -R, rows_out + R - 1), 0, H - 1) * W;
+        w0[u] = wi[qrow + cm];
+        const int64_t p = (int64_t)(y0 + clampi(r - 2 * R, 0, rows_out - 1)) * W + cm;
+        e0[u] = j1[p];
+        e1[u] = j2[p];
+        e2[u] = j3[p];
+    };
+
+    double ring1[2 * R + 1], ring2[2 * R + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) ring1[j] = ring2[j] = 0.0;
+    double s_ab = 0.0, s_bb = 0.0, last_s2 = 0.0;
+
+    const int r_end = rows_out + 2 * R;
+#pragma unroll
+    for (int u = 0; u < P; ++u) fetch(u, -2 * R + u);
+    for (int rb = -2 * R; rb < r_end; rb += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int r = rb + u;
+            const double y = make_y(m0[u], m1[u], lam);
+            const WT cw = w0[u];
+            const double c0 = e0[u], c1 = e1[u], c2 = e2[u];
+            // ---- stage 1: reblurred row r - R, ratio ----
+            lds_wave_order();
+            srow1[R + lane] = y;
+            lds_wave_order();
+            double s1 = a.tp.k[0] * srow1[lane];
+#pragma unroll
+            for (int j = 1; j <= 2 * R; ++j) s1 = s1 + a.tp.k[j] * srow1[lane + j];
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) ring1[j] = ring1[j + 1];
+            ring1[2 * R] = s1;
+            double rbl = a.tp.k[R] * ring1[R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) rbl = rbl + a.tp.k[R + j] * (ring1[R + j] + ring1[R - j]);
+            rbl = rbl < EPS ? EPS : rbl;                       // np.clip(reblurred, eps, None)
+            const double ratio = (double)cw / rbl + EPS;       // cv2.divide; imR += eps
+            // ---- stage 2: blurred ratio row r - 2R ----
+            srow2[R + lane] = ratio;
+            lds_wave_order();
+            double s2;
+            if (!border_x) {
+                s2 = a.tp.k[0] * srow2[lane];
+#pragma unroll
+                for (int j = 1; j <= 2 * R; ++j) s2 = s2 + a.tp.k[j] * srow2[lane + j];
+            } else {
+                // tap j sits at column gx - R + j: replicate the image's edge columns
+                const int off = 2 * R - x0 + R;                // column -> srow2 index
+                s2 = a.tp.k[0] * srow2[clampi(gx - R, 0, W - 1) + off];
+#pragma unroll
+                for (int j = 1; j <= 2 * R; ++j)
+                    s2 = s2 + a.tp.k[j] * srow2[clampi(gx - R + j, 0, W - 1) + off];
+            }
+            const int gq = y0 + r - R;                          // image row of this ratio row
+            if (gq >= H) s2 = last_s2;                          // below the bottom edge
+            last_s2 = s2;
+            if (gq == 0) {                                      // rows above the top edge
+#pragma unroll
+                for (int j = 0; j <= 2 * R; ++j) ring2[j] = s2;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2 * R; ++j) ring2[j] = ring2[j + 1];
+                ring2[2 * R] = s2;
+            }
+            double o = a.tp.k[R] * ring2[R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) o = o + a.tp.k[R + j] * (ring2[R + j] + ring2[R - j]);
+            // ---- epilogue: output row r - 2R ----
+            const int ro = r - 2 * R;
+            const bool ok = ro >= 0 && ro < rows_out && out_lane;
+            const double yo = make_y(c0, c1, lam);              // Y at the output pixel
+            const double jn = yo * o;                           // np.multiply(Y, imR, out=J1)
+            const double tn = jn - yo;                          // np.subtract(J1, Y, out=T1)
+            const double to = c0 - make_y(c1, c2, lam_prev);    // the T1 of the last iteration
+            if (ok) a.jnew[base + (int64_t)(y0 + ro) * W + gx] = jn;
+            s_ab = s_ab + (ok ? tn * to : 0.0);                 // cv2.multiply(T1, T2) summed
+            s_bb = s_bb + (ok ? to * to : 0.0);
+            // the slot's values are dead now: refill it (no copy of a load target)
+            fetch(u, r + P);
+        }
+    }
+    // strip partials -> last strip of the frame -> next lambda (as lr_stream_kernel)
+    s_ab = wave_sum(s_ab);
+    s_bb = wave_sum(s_bb);
+    unsigned ticket = 0;
+    if (lane == 0) {
+        double *pp = a.partials + ((int64_t)img * a.tiles + t) * 2;
+        atomic_store_f64(pp, s_ab);
+        atomic_store_f64(pp + 1, s_bb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket = atomicAdd(a.counters + img, 1u);
+    }
+    ticket = __shfl(ticket, 0, 64);
+    if (ticket != (unsigned)a.tiles - 1u) return;
+    const double *pp = a.partials + (int64_t)img * a.tiles * 2;
+    double ab = 0.0, bb = 0.0;
+    constexpr int U = 8;
+    for (int i0 = lane; i0 < a.tiles; i0 += 64 * U) {
+        double va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u;
+            va[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i) : 0.0;
+            vb[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i + 1) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + 64 * u < a.tiles) { ab = ab + va[u]; bb = bb + vb[u]; }
+        }
+    }
+    ab = wave_sum(ab);
+    bb = wave_sum(bb);
+    if (lane == 0) {
+        double l = ab / (bb + EPS);                   // deconvolve.py:110
+        l = 1.0 < l ? 1.0 : l;                        // min(l, 1)
+        l = 0.0 > l ? 0.0 : l;                        // max(., 0)
+        if (a.iter + 1 <= 1) l = 0.0;                 // acceleration starts at the third iteration
+        a.lam_next[img] = l;
+        if (a.lam_trace) a.lam_trace[(int64_t)img * a.trace_stride + a.iter + 1] = l;
+        a.counters[img] = 0u;
+    }
+}
+
 template <typename WT>
 __global__ void __launch_bounds__(NT) lr_init_kernel(const WT *wi, double *ja, double *jb, double *t1,
-                                                     int64_t n)
+                                                     int64_t n, int fused)
 {
     const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (i < n) {
         const double v = load_wi(wi, i);
         ja[i] = v;
         jb[i] = v;
-        t1[i] = 0.0;
+        t1[i] = fused ? v : 0.0;     // fused path: the third J buffer
     }
 }
 
@@ -308,7 +489,7 @@ __global__ void lr_reset_kernel(double *lam, double *lam_trace, int64_t trace_st
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        lam[i] = 0.0;
+        lam[i] = lam[n + i] = lam[2 * n + i] = 0.0;
         counters[i] = 0u;
         if (lam_trace) lam_trace[(int64_t)i * trace_stride] = 0.0;
     }
@@ -462,7 +643,8 @@ struct Workspace {
 void layout_workspace(int batch, int H, int W, unsigned char *base, Workspace &ws)
 {
     const size_t hw = (size_t)H * W;
-    const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + SEG - 1) / SEG);
+    // strips of the fused kernel at its narrowest (R = 6: 40 output columns)
+    const size_t tiles = (size_t)((W + 39) / 40) * ((H + SEG - 1) / SEG);
     size_t off = 0;
     auto take = [&](size_t bytes) { unsigned char *p = base + off; off += align256(bytes); return p; };
     ws.ja = reinterpret_cast<double *>(take(batch * hw * 8));
@@ -471,7 +653,7 @@ void layout_workspace(int batch, int H, int W, unsigned char *base, Workspace &w
     ws.ratio = reinterpret_cast<double *>(take(batch * hw * 8));
     ws.wi16 = reinterpret_cast<uint16_t *>(take(batch * hw * 2));
     ws.partials = reinterpret_cast<double *>(take(batch * tiles * 16));
-    ws.lam = reinterpret_cast<double *>(take((size_t)batch * 2 * 8));
+    ws.lam = reinterpret_cast<double *>(take((size_t)batch * 3 * 8));
     ws.counters = reinterpret_cast<unsigned *>(take((size_t)batch * 4));
     ws.total = off;
 }
@@ -506,6 +688,39 @@ int launch_iteration(const LrArgs &a, int n, hipStream_t s)
     }
 #endif
     return launch_iteration_p<R, MF_LR_PREFETCH, WT>(a, n, s);
+}
+
+template <int R, typename WT>
+int launch_fused(const LrArgs &a, int n, hipStream_t s)
+{
+    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
+    hipLaunchKernelGGL((lr_fused_kernel<R, SEG, MF_LR_PREFETCH, WT>), grid, dim3(64), 0, s, a);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
+template <typename WT>
+int dispatch_fused(int R, const LrArgs &a, int n, hipStream_t s)
+{
+    switch (R) {
+    case 0: return launch_fused<0, WT>(a, n, s);
+    case 1: return launch_fused<1, WT>(a, n, s);
+    case 2: return launch_fused<2, WT>(a, n, s);
+    case 3: return launch_fused<3, WT>(a, n, s);
+    case 4: return launch_fused<4, WT>(a, n, s);
+    case 5: return launch_fused<5, WT>(a, n, s);
+    case 6: return launch_fused<6, WT>(a, n, s);
+    }
+    return mf::fail(MF_EUNSUPPORTED, "deconvolution filter radius %d > 6", R);
+}
+
+// MF_LR_SPLIT=1 (environment, read once): the two-launch iteration
+// (lr_stream_kernel reblur + update through a ratio buffer) instead of the
+// fused one; kept for comparison and as a fall-back.
+bool use_fused()
+{
+    static const bool fused = !(std::getenv("MF_LR_SPLIT") && std::atoi(std::getenv("MF_LR_SPLIT")));
+    return fused;
 }
 
 template <typename WT>
@@ -572,8 +787,9 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
 {
     const int64_t hw = (int64_t)H * W;
     const int64_t total = hw * nb;
+    const bool fused = use_fused();
     hipLaunchKernelGGL(lr_init_kernel<WT>, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, wi,
-                       ws.ja, ws.jb, ws.t1, total);
+                       ws.ja, ws.jb, ws.t1, total, (int)fused);
     double *trace = lam_trace ? lam_trace + (int64_t)i0 * iterations : nullptr;
     hipLaunchKernelGGL(lr_reset_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, ws.lam,
                        iterations > 0 ? trace : nullptr, (int64_t)iterations, ws.counters, nb);
@@ -585,20 +801,27 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
     a.partials = ws.partials;
     a.counters = ws.counters;
     a.H = H; a.W = W;
-    a.tiles_x = (W + TW - 1) / TW;
+    const int strip_w = fused ? TW - 4 * R : TW;
+    a.tiles_x = (W + strip_w - 1) / strip_w;
     a.tiles = a.tiles_x * ((H + SEG - 1) / SEG);
     a.tp = tp;
     a.trace_stride = iterations;
-    double *j1 = ws.ja, *j2 = ws.jb;
+    double *j1 = ws.ja, *j2 = ws.jb, *j3 = ws.t1;
     for (int it = 0; it < iterations; ++it) {
-        a.j1 = j1; a.j2 = j2; a.jnew = j2;
-        a.lam = ws.lam + (size_t)(it & 1) * nb;
-        a.lam_next = ws.lam + (size_t)((it + 1) & 1) * nb;
+        a.j1 = j1; a.j2 = j2; a.j3 = j3;
+        a.jnew = fused ? j3 : j2;
+        a.lam = ws.lam + (size_t)(it % 3) * nb;
+        a.lam_next = ws.lam + (size_t)((it + 1) % 3) * nb;
+        a.lam_prev = ws.lam + (size_t)((it + 2) % 3) * nb;
         a.lam_trace = it + 1 < iterations ? trace : nullptr;
         a.iter = it;
-        int rc = dispatch_iteration<WT>(R, a, nb, s);
+        int rc = fused ? dispatch_fused<WT>(R, a, nb, s) : dispatch_iteration<WT>(R, a, nb, s);
         if (rc) return rc;
-        double *tmp = j1; j1 = j2; j2 = tmp;
+        if (fused) {         // (J1, J2, J3) <- (J1', J1, J2)
+            double *tmp = j3; j3 = j2; j2 = j1; j1 = tmp;
+        } else {
+            double *tmp = j1; j1 = j2; j2 = tmp;
+        }
     }
     void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
                         : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
