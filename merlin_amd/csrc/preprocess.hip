@@ -33,7 +33,7 @@ namespace {
 
 constexpr int TW = 64;          // tile width = wave width
 #ifndef MF_LR_SEG
-#define MF_LR_SEG 64
+#define MF_LR_SEG 128
 #endif
 constexpr int SEG = MF_LR_SEG;  // rows of one deconvolution strip segment
 constexpr int TH = 32;          // tile height: 4 waves x 8 rows
@@ -311,12 +311,20 @@ __global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
 // reads the edge column's ratio (clamped LDS index, border strips only), above
 // the top edge the ring is filled with row 0's row sum, below the bottom edge
 // the last row sum is repeated.
+//
+// The J1 / J2 values of the strip's own columns wait in an LDS ring for the 2R
+// rows between their use as blur input and their use in the epilogue (a second
+// global load missed L2 too often: 384 waves per XCD stream more than its 4 MB
+// between the two uses).
 template <int R, int SEGT, int P, typename WT>
 __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 {
     constexpr int OUTW = TW - 4 * R;
+    constexpr int NRING = 2 * R + 1;
     __shared__ double srow1[TW + 2 * R];
     __shared__ double srow2[TW + 2 * R];
+    __shared__ double sj1[NRING][TW];
+    __shared__ double sj2[NRING][TW];
     const int t = xcd_tile(a.tiles);
     if (t < 0) return;
     const int img = blockIdx.y;
@@ -341,7 +349,7 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 
     // P rows of every stream in flight, in fixed registers: slot u serves loop
     // rows r = -2R + u (mod P): Y row r, ratio row r - R, output row r - 2R
-    double m0[P], m1[P], e0[P], e1[P], e2[P];
+    double m0[P], m1[P], e2[P];
     WT w0[P];
     auto fetch = [&](int u, int r) {
         const int64_t yrow = (int64_t)clampi(y0 + min(r, rows_out + 2 * R - 1), 0, H - 1) * W;
@@ -350,8 +358,6 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
         const int64_t qrow = (int64_t)clampi(y0 + clampi(r - R, -R, rows_out + R - 1), 0, H - 1) * W;
         w0[u] = wi[qrow + cm];
         const int64_t p = (int64_t)(y0 + clampi(r - 2 * R, 0, rows_out - 1)) * W + cm;
-        e0[u] = j1[p];
-        e1[u] = j2[p];
         e2[u] = j3[p];
     };
 
@@ -361,19 +367,26 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
     double s_ab = 0.0, s_bb = 0.0, last_s2 = 0.0;
 
     const int r_end = rows_out + 2 * R;
+    int slot = 0;                      // ring slot of the Y row being consumed
 #pragma unroll
     for (int u = 0; u < P; ++u) fetch(u, -2 * R + u);
     for (int rb = -2 * R; rb < r_end; rb += P) {
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int r = rb + u;
-            const double y = make_y(m0[u], m1[u], lam);
+            const double a1 = m0[u], a2 = m1[u], c2 = e2[u];
+            const double y = make_y(a1, a2, lam);
             const WT cw = w0[u];
-            const double c0 = e0[u], c1 = e1[u], c2 = e2[u];
             // ---- stage 1: reblurred row r - R, ratio ----
             lds_wave_order();
             srow1[R + lane] = y;
+            sj1[slot][lane] = a1;
+            sj2[slot][lane] = a2;
             lds_wave_order();
+            // the row written 2R iterations ago is the output row's
+            const int oslot = slot + 1 == NRING ? 0 : slot + 1;
+            const double c0 = sj1[oslot][lane], c1 = sj2[oslot][lane];
+            slot = oslot;
             double s1 = a.tp.k[0] * srow1[lane];
 #pragma unroll
             for (int j = 1; j <= 2 * R; ++j) s1 = s1 + a.tp.k[j] * srow1[lane + j];
@@ -425,7 +438,11 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
             if (ok) a.jnew[base + (int64_t)(y0 + ro) * W + gx] = jn;
             s_ab = s_ab + (ok ? tn * to : 0.0);                 // cv2.multiply(T1, T2) summed
             s_bb = s_bb + (ok ? to * to : 0.0);
-            // the slot's values are dead now: refill it (no copy of a load target)
+            // the slot's values are dead now: refill it.  The scheduling barrier
+            // keeps the loads from being hoisted above the last use of the old
+            // values, which would cost a register copy (and a wait for the
+            // load) at the loop's back edge.
+            __builtin_amdgcn_sched_barrier(0);
             fetch(u, r + P);
         }
     }

@@ -21,13 +21,14 @@ from merlin_amd import _lib
 HIST_BINS = _lib.MF_HIST_BINS
 # working set per pixel and image inside mf_deconvolve_lucyrichardson
 _BYTES_PER_PIXEL = 34
-_WORKSPACE_TARGET = 2 << 30
+_WORKSPACE_TARGET = 4 << 30
 
 
 def default_batch(H: int, W: int) -> int:
-    """Images deconvolved per launch: about 2 GiB of workspace (15 frames of
-    2048 x 2048), between 1 and 64.  Measured: 1.43 ms per frame from batch 2
-    to batch 14, 1.7 ms at batch 1 (too few waves to fill the chip)."""
+    """Images deconvolved per launch: about 4 GiB of workspace (30 frames of
+    2048 x 2048), between 1 and 64.  Measured per 2048 x 2048 frame: 0.80 ms at
+    batch 28, 0.85 at 14, 0.89 at 7, 1.6 at 1 (too few waves to fill the chip,
+    and every launch ends with a partly filled last round of strips)."""
     return max(1, min(64, _WORKSPACE_TARGET // (_BYTES_PER_PIXEL * H * W)))
 
 
