@@ -5,19 +5,17 @@
 // merlin/util/deconvolve.py:70-133 (deconvolve_lucyrichardson, odd windows) and
 // merlin/analysis/preprocess.py:114-140 (_preprocess_image + pixel histogram).
 //
-// The deconvolution is float64 like the reference and bound by memory traffic:
-// per iteration and pixel it reads J1, J2 (twice), the observed image, the
-// previous difference T1 and the ratio, and writes the ratio, the new J1 and T1
-// (74 B/px with a uint16 observed image).  Two launches per iteration
-// (lr_stream_kernel, UPDATE = false / true), each a grid of single-wave
-// workgroups that stream 64-column strips through a register ring; the sums
-// behind the acceleration parameter are reduced in a fixed order.
+// The deconvolution is float64 like the reference and bound by memory traffic.
+// One launch per iteration (lr_fused_kernel): single-wave workgroups stream
+// 64-column strips through both blurs of the iteration, so that per pixel only
+// J1, J2, J3 and the observed image are read and the new J1 written (34 B);
+// the sums behind the acceleration parameter are reduced in a fixed order.
+// lr_stream_kernel (two launches per iteration through a stored ratio image,
+// 74 B) is the earlier form, kept behind MF_LR_SPLIT=1.
 //
-// Images are processed `batch` at a time (one launch covers the batch; the
-// working set is 34 B/px per image).  Measured on MI355X the batch size hardly
-// matters (1.43 ms per 2048 x 2048 frame at batch 2, inside the Infinity Cache,
-// and at batch 14, far outside it): the kernels run at the mixed read/write
-// rate of the memory system either way.
+// Frames are processed `batch` at a time (one launch covers the batch; the
+// working set is 34 B/px per frame); large batches keep the chip filled to the
+// end of each launch.
 //
 // Built with -ffp-contract=off: every product and sum below rounds on its own,
 // as the non-FMA scalar path of OpenCV and numpy do.
