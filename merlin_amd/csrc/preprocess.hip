@@ -310,10 +310,11 @@ __global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
 // the top edge the ring is filled with row 0's row sum, below the bottom edge
 // the last row sum is repeated.
 //
-// The J1 / J2 values of the strip's own columns wait in an LDS ring for the 2R
-// rows between their use as blur input and their use in the epilogue (a second
-// global load missed L2 too often: 384 waves per XCD stream more than its 4 MB
-// between the two uses).
+// Y and the rebuilt T1 of the strip's own columns wait in an LDS ring for the 2R
+// rows between the blur input and the epilogue (a second global load of J1 / J2
+// there missed L2 too often: 384 waves per XCD stream more than its 4 MB
+// between the two uses), so every loaded register is dead within the row it is
+// consumed in.
 template <int R, int SEGT, int P, typename WT>
 __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 {
@@ -355,7 +356,8 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
         m1[u] = j2[yrow + cm];
         const int64_t qrow = (int64_t)clampi(y0 + clampi(r - R, -R, rows_out + R - 1), 0, H - 1) * W;
         w0[u] = wi[qrow + cm];
-        const int64_t p = (int64_t)(y0 + clampi(r - 2 * R, 0, rows_out - 1)) * W + cm;
+        // J3 is only needed where row r is one of the strip's own output rows
+        const int64_t p = (int64_t)(y0 + clampi(r, 0, rows_out - 1)) * W + cm;
         e2[u] = j3[p];
     };
 
@@ -372,18 +374,20 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int r = rb + u;
-            const double a1 = m0[u], a2 = m1[u], c2 = e2[u];
+            const double a1 = m0[u], a2 = m1[u];
             const double y = make_y(a1, a2, lam);
+            // the T1 of the last iteration at this pixel, rebuilt: J1 - Y_prev
+            const double told = a1 - make_y(a2, e2[u], lam_prev);
             const WT cw = w0[u];
             // ---- stage 1: reblurred row r - R, ratio ----
             lds_wave_order();
             srow1[R + lane] = y;
-            sj1[slot][lane] = a1;
-            sj2[slot][lane] = a2;
+            sj1[slot][lane] = y;
+            sj2[slot][lane] = told;
             lds_wave_order();
             // the row written 2R iterations ago is the output row's
             const int oslot = slot + 1 == NRING ? 0 : slot + 1;
-            const double c0 = sj1[oslot][lane], c1 = sj2[oslot][lane];
+            const double yo = sj1[oslot][lane], to = sj2[oslot][lane];
             slot = oslot;
             double s1 = a.tp.k[0] * srow1[lane];
 #pragma unroll
@@ -429,10 +433,8 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
             // ---- epilogue: output row r - 2R ----
             const int ro = r - 2 * R;
             const bool ok = ro >= 0 && ro < rows_out && out_lane;
-            const double yo = make_y(c0, c1, lam);              // Y at the output pixel
             const double jn = yo * o;                           // np.multiply(Y, imR, out=J1)
             const double tn = jn - yo;                          // np.subtract(J1, Y, out=T1)
-            const double to = c0 - make_y(c1, c2, lam_prev);    // the T1 of the last iteration
             if (ok) a.jnew[base + (int64_t)(y0 + ro) * W + gx] = jn;
             s_ab = s_ab + (ok ? tn * to : 0.0);                 // cv2.multiply(T1, T2) summed
             s_bb = s_bb + (ok ? to * to : 0.0);
