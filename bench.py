@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-pipeline', action='store_true')
+    ap.add_argument('--no-preprocess', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -204,6 +205,39 @@ def main():
                              'H2D of FOV k+1 overlaps the kernels of FOV k'}
         del hosts
 
+    # ---- the stage in front of the decoder, reported beside
+    # the headline number: high-pass + 20 float64 Lucy-Richardson iterations per
+    # 2048 x 2048 camera frame (112 frames make one FOV) ----
+    pre_line = None
+    if rank == 0 and not args.no_preprocess:
+        from merlin_amd.preprocess import DeconvolutionPreprocess
+        n_frames = 28
+        g = torch.Generator(device=dev).manual_seed(SEED)
+        frames = (2000 + fovs[0][:4].reshape(-1, H, W)[:n_frames].float()
+                  + 10 * torch.randn((n_frames, H, W), device=dev, generator=g)
+                  ).clamp_(0, 65535).to(torch.uint16)
+        pre = DeconvolutionPreprocess(device=dev, batch=n_frames)
+        pre.preprocess_device(frames)
+        torch.cuda.synchronize(dev)
+        p0 = torch.cuda.Event(enable_timing=True)
+        p1 = torch.cuda.Event(enable_timing=True)
+        p0.record()
+        for _ in range(3):
+            pre.preprocess_device(frames)
+        p1.record()
+        torch.cuda.synchronize(dev)
+        ms_frame = p0.elapsed_time(p1) / 3 / n_frames
+        pre_bytes = (34 * 20 + 40) * H * W
+        pre_line = {'ms_per_frame': ms_frame, 'Mpx_per_s': H * W / ms_frame / 1e3,
+                    'ms_per_fov': ms_frame * B * Z, 'dtype': 'f64',
+                    'roofline': {'bound': 'hbm', 'achieved': pre_bytes / ms_frame / 1e6,
+                                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': pre_bytes / ms_frame / 1e6 / HBM_PEAK_GBS},
+                    'note': 'camera frames (offset 2000 + the synthetic FOV) -> uint16 stack + '
+                            'pixel histogram; {} frames per launch'.format(n_frames)}
+        del frames, pre
+        torch.cuda.empty_cache()
+
     if rank == 0:
         mpx = world * args.steps * px_fov / dt / 1e6
         out = {
@@ -231,6 +265,8 @@ def main():
         }
         if host_line is not None:
             out['host_pipeline'] = host_line
+        if pre_line is not None:
+            out['preprocess'] = pre_line
         if not args.no_cpu_baseline and world == 1:
             plane = fovs[0][:, 0].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(codebook, plane, sf, bg,
