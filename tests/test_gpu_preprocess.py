@@ -242,3 +242,18 @@ def test_preprocess_feeds_decode(gpu_device):
     r, e = frame_to_array(bc, B), frame_to_array(exp, B)
     assert r.shape == e.shape and len(r) > 10
     np.testing.assert_allclose(r, e, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (3, 5), (1, 200), (200, 1), (9, 9), (130, 47), (257, 64)])
+def test_lucy_richardson_small_and_odd_shapes(gpu_device, shape):
+    """Strips narrower / shorter than a wave's 64 x 128 window, images smaller
+    than the blur radius: every border path of the fused kernel."""
+    from merlin_amd import preprocess as pp
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = rng.integers(0, 3000, size=shape).astype(np.float64)
+    img[rng.random(shape) < 0.5] = 0.0
+    for window, sigma in ((9, 2.0), (13, 3.0)):
+        assert np.array_equal(pp.deconvolve_lucyrichardson(img, window, sigma, 2),
+                              po.deconvolve_lucyrichardson(img, window, sigma, 2))
+        check_f64(pp.deconvolve_lucyrichardson(img, window, sigma, 9),
+                  po.deconvolve_lucyrichardson(img, window, sigma, 9))
