@@ -226,6 +226,21 @@ int mf_deconvolve_lucyrichardson(const void *image, int image_dtype,
                                  void *workspace, int64_t workspace_bytes,
                                  void *stream);
 
+/* deconvolve_lucyrichardson_guo (merlin/util/deconvolve.py:136-174), what
+ * DeconvolutionPreprocessGuo runs (analysis/preprocess.py:143-164): per
+ * iteration two cv2.filter2D correlations (BORDER_REPLICATE) with the forward
+ * and backward projectors of calculate_projectors (deconvolve.py:13-67).
+ *   h_pf, h_pb  HOST f64 [window_size, window_size], window_size odd <= 13
+ * Other arguments as mf_deconvolve_lucyrichardson (same workspace). */
+int mf_deconvolve_lucyrichardson_guo(const void *image, int image_dtype,
+                                     int n_images, int H, int W,
+                                     int window_size, const double *h_pf,
+                                     const double *h_pb, int iterations,
+                                     void *out, int out_dtype,
+                                     int64_t *histogram, int hist_group,
+                                     int batch, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
+
 /* DeconvolutionPreprocess._preprocess_image (analysis/preprocess.py:133-140)
  * for n_images camera frames: high-pass (highpass_sigma), Lucy-Richardson
  * (decon_filter_size, decon_sigma, decon_iterations), uint16 hand-over, plus

@@ -616,6 +616,74 @@ __global__ void __launch_bounds__(NT) high_pass_kernel(const HpArgs a)
     }
 }
 
+// ---- Guo et al. variant (deconvolve.py:136-174) ------------------------------
+// ek <- clip(ek * filter2D(image / clip(filter2D(ek, pf), eps, 65535), pb), eps,
+// 65535) with two non-separable K x K projectors (K <= 13) supplied by the host
+// (they come out of an FFT, deconvolve.py:13-67).  cv2.filter2D is a correlation
+// anchored at the kernel centre, BORDER_REPLICATE; OpenCV adds the non-zero taps
+// in row-major order.  Two iterations by default: a plain LDS-tiled kernel.
+constexpr int GUO_MAXK = 13;
+constexpr int GUO_TH = 16;
+constexpr double GUO_EPS = 1.0e-6, GUO_IMAX = 65535.0;
+
+struct GuoArgs {
+    const void *img;      // observed image(s) [n][HW], u16 or f64
+    double *ek;           // estimate, updated in place by the backward step
+    double *ratio;        // image / forward projection
+    int H, W, K, tiles_x, tiles, backward;
+    double k[GUO_MAXK * GUO_MAXK];
+};
+
+__device__ __forceinline__ double clip_guo(double v)
+{
+    v = v < GUO_EPS ? GUO_EPS : v;
+    return v > GUO_IMAX ? GUO_IMAX : v;
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(NT) guo_step_kernel(const GuoArgs a)
+{
+    __shared__ double tile[(GUO_TH + GUO_MAXK - 1) * (TW + GUO_MAXK - 1)];
+    const int t = xcd_tile(a.tiles);
+    if (t < 0) return;
+    const int K = a.K, R = K / 2, IW = TW + 2 * R, IH = GUO_TH + 2 * R;
+    const int H = a.H, W = a.W;
+    const int64_t base = (int64_t)blockIdx.y * H * W;
+    const double *src = (a.backward ? a.ratio : a.ek) + base;
+    const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * GUO_TH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < IW * IH; e += NT) {
+        const int r = e / IW, c = e - r * IW;
+        tile[e] = src[(int64_t)clampi(y0 - R + r, 0, H - 1) * W + clampi(x0 - R + c, 0, W - 1)];
+    }
+    __syncthreads();
+    const int gx = x0 + lane;
+    const WT *img = reinterpret_cast<const WT *>(a.img) + base;
+    for (int o = 0; o < GUO_TH / 4; ++o) {
+        const int ly = wave * (GUO_TH / 4) + o, gy = y0 + ly;
+        if (gy >= H || gx >= W) continue;
+        double s = 0.0;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                const double kv = a.k[i * K + j];
+                if (kv != 0.0) s = s + kv * tile[(ly + i) * IW + lane + j];
+            }
+        const int64_t p = base + (int64_t)gy * W + gx;
+        if (a.backward) a.ek[p] = clip_guo(a.ek[p] * s);
+        else a.ratio[p] = load_wi(img, p - base) / clip_guo(s);
+    }
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(NT) guo_init_kernel(const WT *img, double *ek, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n) {
+        const double v = load_wi(img, i);
+        ek[i] = v < GUO_EPS ? GUO_EPS : v;          // np.clip(ek, eps, None)
+    }
+}
+
 int fill_taps(int ksize, double sigma, Taps &tp)
 {
     if (ksize < 1 || !(ksize & 1) || ksize > 2 * MF_PP_MAX_RADIUS + 1)
@@ -848,7 +916,83 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
     return MF_OK;
 }
 
+template <typename WT>
+int run_guo_batch(const WT *img, int nb, int i0, int H, int W, int K, const double *h_pf,
+                  const double *h_pb, int iterations, void *out, int out_f64,
+                  unsigned long long *hist, int hist_group, Workspace &ws, hipStream_t s)
+{
+    const int64_t hw = (int64_t)H * W, total = hw * nb;
+    hipLaunchKernelGGL(guo_init_kernel<WT>, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, img,
+                       ws.ja, total);
+    GuoArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.img = img;
+    a.ek = ws.ja;
+    a.ratio = ws.jb;
+    a.H = H; a.W = W; a.K = K;
+    a.tiles_x = (W + TW - 1) / TW;
+    a.tiles = a.tiles_x * ((H + GUO_TH - 1) / GUO_TH);
+    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)nb);
+    for (int it = 0; it < iterations; ++it) {
+        a.backward = 0;
+        std::memcpy(a.k, h_pf, sizeof(double) * K * K);
+        hipLaunchKernelGGL(guo_step_kernel<WT>, grid, dim3(NT), 0, s, a);
+        a.backward = 1;
+        std::memcpy(a.k, h_pb, sizeof(double) * K * K);
+        hipLaunchKernelGGL(guo_step_kernel<WT>, grid, dim3(NT), 0, s, a);
+    }
+    void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
+                        : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
+    hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, ws.ja, dst,
+                       out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
 }  // namespace
+
+extern "C" int mf_deconvolve_lucyrichardson_guo(const void *image, int image_dtype, int n_images, int H,
+                                                int W, int window_size, const double *h_pf,
+                                                const double *h_pb, int iterations, void *out,
+                                                int out_dtype, int64_t *histogram, int hist_group,
+                                                int batch, void *workspace, int64_t workspace_bytes,
+                                                void *stream)
+{
+    if (!image || !out || !workspace || !h_pf || !h_pb)
+        return mf::fail(MF_EINVAL, "null pointer argument");
+    int rc = check_shape(n_images, H, W, batch);
+    if (rc) return rc;
+    if (image_dtype != MF_DTYPE_U16 && image_dtype != MF_DTYPE_F64)
+        return mf::fail(MF_EINVAL, "image dtype %d not u16/f64", image_dtype);
+    if (out_dtype != MF_DTYPE_U16 && out_dtype != MF_DTYPE_F64)
+        return mf::fail(MF_EINVAL, "output dtype %d not u16/f64", out_dtype);
+    if (iterations < 0) return mf::fail(MF_EINVAL, "iteration count %d < 0", iterations);
+    if (window_size < 1 || !(window_size & 1) || window_size > GUO_MAXK)
+        return mf::fail(MF_EUNSUPPORTED, "projector window %d must be odd and <= %d", window_size,
+                        GUO_MAXK);
+    if (histogram && (out_dtype != MF_DTYPE_U16 || hist_group < 1))
+        return mf::fail(MF_EINVAL, "histogram needs uint16 output and hist_group >= 1");
+    Workspace ws;
+    layout_workspace(batch, H, W, reinterpret_cast<unsigned char *>(workspace), ws);
+    if ((int64_t)ws.total > workspace_bytes)
+        return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes", (long long)workspace_bytes,
+                        (long long)ws.total);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t hw = (int64_t)H * W;
+    for (int i0 = 0; i0 < n_images; i0 += batch) {
+        const int nb = n_images - i0 < batch ? n_images - i0 : batch;
+        if (image_dtype == MF_DTYPE_U16)
+            rc = run_guo_batch(reinterpret_cast<const uint16_t *>(image) + i0 * hw, nb, i0, H, W,
+                               window_size, h_pf, h_pb, iterations, out, out_dtype == MF_DTYPE_F64,
+                               reinterpret_cast<unsigned long long *>(histogram), hist_group, ws, s);
+        else
+            rc = run_guo_batch(reinterpret_cast<const double *>(image) + i0 * hw, nb, i0, H, W,
+                               window_size, h_pf, h_pb, iterations, out, out_dtype == MF_DTYPE_F64,
+                               reinterpret_cast<unsigned long long *>(histogram), hist_group, ws, s);
+        if (rc) return rc;
+    }
+    return MF_OK;
+}
 
 extern "C" int64_t mf_preprocess_workspace_bytes(int batch, int H, int W)
 {

@@ -148,6 +148,88 @@ def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
         t, windowSize, sigmaG, iterationCount).cpu().numpy()
 
 
+def matlab_gauss2D(shape=(3, 3), sigma=0.5) -> np.ndarray:
+    """merlin/util/matlab.py:11-24: MATLAB's fspecial('gaussian', shape, sigma)."""
+    m, n = [(ss - 1.) / 2. for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2. * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    sumh = h.sum()
+    if sumh != 0:
+        h /= sumh
+    return h
+
+
+def calculate_projectors(windowSize: int, sigmaG: float) -> list:
+    """deconvolve.py:13-67: the Gaussian forward projector and the
+    Wiener-Butterworth back projector of Guo et al. (alpha = beta = 0.001,
+    order 8, cut-off 1 / (0.5 * 2.355 * sigma)).  Host work: two windowSize^2
+    FFTs."""
+    pf = matlab_gauss2D(shape=(windowSize, windowSize), sigma=sigmaG)
+    spectrum = np.fft.fft2(pf)
+    alpha, beta, order = 0.001, 0.001, 8
+    cutoff = 1.0 / (0.5 * 2.355 * sigmaG)
+    freq = np.fft.fftfreq(spectrum.shape[0])
+    kx = np.tile(freq, (freq.size, 1))
+    radius = np.sqrt(kx * kx + kx.T * kx.T)
+    wiener = spectrum / (np.abs(spectrum) * np.abs(spectrum) + alpha)
+    ripple = np.sqrt(1.0 / (beta * beta) - 1)
+    butterworth = 1.0 / np.sqrt(
+        1.0 + ripple * ripple * np.power(radius * radius / (cutoff * cutoff), order))
+    pb = np.real(np.fft.ifft2(wiener * butterworth))
+    return [pf, pb]
+
+
+def deconvolve_lucyrichardson_guo_device(
+        image: torch.Tensor, windowSize: int, sigmaG: float,
+        iterationCount: int, out_dtype=torch.float64,
+        histogram: Optional[torch.Tensor] = None, hist_group: int = 1,
+        batch: Optional[int] = None) -> torch.Tensor:
+    """deconvolve_lucyrichardson_guo (deconvolve.py:136-174) for images
+    [..., H, W] (uint16 or float64) on the GPU."""
+    import ctypes
+    if image.dtype == torch.uint16:
+        dt = _lib.MF_DTYPE_U16
+    elif image.dtype == torch.float64:
+        dt = _lib.MF_DTYPE_F64
+    else:
+        raise NotImplementedError('image must be uint16 or float64')
+    if out_dtype not in (torch.float64, torch.uint16):
+        raise ValueError('out_dtype must be float64 or uint16')
+    if windowSize % 2 != 1:
+        raise NotImplementedError('projector windows must be odd')
+    pf, pb = [np.ascontiguousarray(k, dtype=np.float64)
+              for k in calculate_projectors(windowSize, sigmaG)]
+    flat, shape = _as_images(image)
+    n, H, W = flat.shape
+    dev = flat.device
+    if batch is None:
+        batch = default_batch(H, W)
+    batch = max(1, min(int(batch), max(n, 1)))
+    out = torch.empty((n, H, W), dtype=out_dtype, device=dev)
+    dp = ctypes.POINTER(ctypes.c_double)
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, batch, H, W)
+        _lib.check(_lib.lib().mf_deconvolve_lucyrichardson_guo(
+            flat.data_ptr(), dt, n, H, W, int(windowSize),
+            pf.ctypes.data_as(dp), pb.ctypes.data_as(dp), int(iterationCount),
+            out.data_ptr(),
+            _lib.MF_DTYPE_F64 if out_dtype == torch.float64 else _lib.MF_DTYPE_U16,
+            None if histogram is None else histogram.data_ptr(), int(hist_group),
+            batch, ws.data_ptr(), ws.numel(), _stream_ptr(dev)))
+    return out.reshape(shape)
+
+
+def deconvolve_lucyrichardson_guo(image: np.ndarray, windowSize: int,
+                                  sigmaG: float,
+                                  iterationCount: int) -> np.ndarray:
+    """Drop-in for merlin.util.deconvolve.deconvolve_lucyrichardson_guo."""
+    dev = _device()
+    t = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float64)).to(dev)
+    return deconvolve_lucyrichardson_guo_device(
+        t, windowSize, sigmaG, iterationCount).cpu().numpy()
+
+
 class DeconvolutionPreprocess(object):
     """Image arithmetic of merlin.analysis.preprocess.DeconvolutionPreprocess.
 
@@ -228,4 +310,38 @@ class DeconvolutionPreprocess(object):
                 out.data_ptr(), None if hist is None else hist.data_ptr(),
                 int(hist_group), batch, ws.data_ptr(), ws.numel(),
                 _stream_ptr(dev)))
+        return out.reshape(shape), hist
+
+
+class DeconvolutionPreprocessGuo(DeconvolutionPreprocess):
+    """merlin.analysis.preprocess.DeconvolutionPreprocessGuo (preprocess.py:
+    143-164): the same stage with the Guo et al. iteration, 2 iterations unless
+    the caller sets ``decon_iterations``."""
+
+    def __init__(self, parameters=None, device=None, batch=None):
+        super().__init__(parameters, device, batch)
+        if 'decon_iterations' not in (parameters or {}):
+            self.parameters['decon_iterations'] = 2
+        self._deconIterations = self.parameters['decon_iterations']
+
+    def preprocess_device(self, images: torch.Tensor, histogram: bool = True,
+                          hist_group: Optional[int] = None
+                          ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if images.dtype != torch.uint16:
+            raise NotImplementedError('camera frames must be uint16')
+        flat, shape = _as_images(images)
+        n, H, W = flat.shape
+        if hist_group is None:
+            hist_group = shape[1] if len(shape) == 4 else 1
+        hist = None
+        if histogram:
+            hist = torch.zeros(((n + hist_group - 1) // hist_group, HIST_BINS),
+                               dtype=torch.int64, device=flat.device)
+        highPassFilterSize = int(2 * np.ceil(2 * self._highPassSigma) + 1)
+        hp = high_pass_filter_device(flat, highPassFilterSize,
+                                     self._highPassSigma)
+        out = deconvolve_lucyrichardson_guo_device(
+            hp, int(self.parameters['decon_filter_size']), self._deconSigma,
+            self._deconIterations, out_dtype=torch.uint16, histogram=hist,
+            hist_group=hist_group, batch=self._batch)
         return out.reshape(shape), hist

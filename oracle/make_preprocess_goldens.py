@@ -74,6 +74,12 @@ def install_shims():
         dst[...] = q
         return dst
 
+    def filter2D(src, ddepth, kernel, borderType=None):
+        assert ddepth == -1 and borderType == cv2.BORDER_REPLICATE
+        return po.filter2d_f64_replicate(np.ascontiguousarray(src, dtype=np.float64),
+                                         np.asarray(kernel, dtype=np.float64))
+
+    cv2.filter2D = filter2D
     cv2.GaussianBlur = GaussianBlur
     cv2.subtract = subtract
     cv2.addWeighted = addWeighted
@@ -146,6 +152,19 @@ def main():
     z = np.zeros((40, 40), dtype=np.uint16)
     z[20, 20] = 1000
     run_case('pp_point', deconvolve, imagefilters, z, iterations=5)
+
+    # the Guo et al. variant (DeconvolutionPreprocessGuo: 2 iterations by default)
+    for name, img, size, sigma, its in (
+            ('ppguo_synth', camera_image((72, 100), 30, seed=5), 9, 2, 2),
+            ('ppguo_sat', camera_image((64, 64), 25, seed=6, saturate=True), 9, 2, 3),
+            ('ppguo_params', camera_image((50, 70), 20, seed=7), 7, 1.5, 4)):
+        hp = imagefilters.high_pass_filter(img, 13, 3)
+        pf, pb = deconvolve.calculate_projectors(size, sigma)
+        dec = deconvolve.deconvolve_lucyrichardson_guo(hp.astype(float), size, sigma, its)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), image=img, highpass=hp, pf=pf,
+                            pb=pb, deconvolved=dec, output=dec.astype(np.uint16),
+                            params=np.array([3, sigma, size, its], dtype=np.float64))
+        print('{:24s} max={:9.1f}'.format(name, dec.max()))
 
 
 if __name__ == '__main__':

@@ -166,3 +166,74 @@ def pixel_histogram(images: np.ndarray) -> np.ndarray:
     out = c[:65534].copy()
     out[65533] += c[65534]
     return out
+
+
+# --------------------------------------------------------------------------
+# Guo et al. variant (DeconvolutionPreprocessGuo, preprocess.py:143-164)
+# --------------------------------------------------------------------------
+
+def matlab_gauss2D(shape=(3, 3), sigma=0.5) -> np.ndarray:
+    """merlin/util/matlab.py:11-24 (fspecial('gaussian'))."""
+    m, n = [(ss - 1.) / 2. for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2. * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    sumh = h.sum()
+    if sumh != 0:
+        h /= sumh
+    return h
+
+
+def calculate_projectors(windowSize: int, sigmaG: float):
+    """deconvolve.py:13-67: Gaussian forward projector and the
+    Wiener-Butterworth back projector of Guo et al."""
+    pf = matlab_gauss2D(shape=(windowSize, windowSize), sigma=sigmaG)
+    pfFFT = np.fft.fft2(pf)
+    alpha, beta, n = 0.001, 0.001, 8
+    kc = 1.0 / (0.5 * 2.355 * sigmaG)
+    kv = np.fft.fftfreq(pfFFT.shape[0])
+    kx = np.tile(kv, (kv.size, 1))
+    ky = np.transpose(kx)
+    kk = np.sqrt(kx * kx + ky * ky)
+    bWiener = pfFFT / (np.abs(pfFFT) * np.abs(pfFFT) + alpha)
+    eps = np.sqrt(1.0 / (beta * beta) - 1)
+    kkSqr = kk * kk / (kc * kc)
+    bBWorth = 1.0 / np.sqrt(1.0 + eps * eps * np.power(kkSqr, n))
+    pb = np.real(np.fft.ifft2(bWiener * bBWorth))
+    return [pf, pb]
+
+
+def filter2d_f64_replicate(img: np.ndarray, kernel: np.ndarray) -> np.ndarray:
+    """cv2.filter2D(img, -1, kernel, borderType=BORDER_REPLICATE) on float64:
+    correlation anchored at the kernel centre; OpenCV's Filter2D adds the
+    non-zero taps in row-major kernel order, every product and sum rounded on
+    its own.  Parity unpinned (cv2 absent)."""
+    assert img.dtype == np.float64 and img.ndim == 2
+    kh, kw = kernel.shape
+    ry, rx = kh // 2, kw // 2
+    h, w = img.shape
+    p = np.pad(img, ((ry, ry), (rx, rx)), mode='edge')
+    out = np.zeros((h, w))
+    for i in range(kh):
+        for j in range(kw):
+            if kernel[i, j] != 0:
+                out = out + kernel[i, j] * p[i:i + h, j:j + w]
+    return out
+
+
+def deconvolve_lucyrichardson_guo(image: np.ndarray, windowSize: int,
+                                  sigmaG: float, iterationCount: int
+                                  ) -> np.ndarray:
+    """deconvolve.py:136-174"""
+    pf, pb = calculate_projectors(windowSize, sigmaG)
+    eps = 1.0e-6
+    i_max = 2 ** 16 - 1
+    image = np.asarray(image, dtype=np.float64)
+    ek = np.copy(image)
+    np.clip(ek, eps, None, ek)
+    for _ in range(iterationCount):
+        ekf = filter2d_f64_replicate(ek, pf)
+        np.clip(ekf, eps, i_max, ekf)
+        ek = ek * filter2d_f64_replicate(image / ekf, pb)
+        np.clip(ek, eps, i_max, ek)
+    return ek

@@ -257,3 +257,39 @@ def test_lucy_richardson_small_and_odd_shapes(gpu_device, shape):
                               po.deconvolve_lucyrichardson(img, window, sigma, 2))
         check_f64(pp.deconvolve_lucyrichardson(img, window, sigma, 9),
                   po.deconvolve_lucyrichardson(img, window, sigma, 9))
+
+
+def test_guo_variant(gpu_device):
+    """deconvolve_lucyrichardson_guo / DeconvolutionPreprocessGuo against the
+    reference-made goldens and the oracle.  The projectors come out of an FFT
+    (different builds differ in the last bits), so the comparison with the
+    golden is to 1e-9; with the oracle fed the same projectors the non-separable
+    filter is the same sum in the same order: bit-exact."""
+    import glob, os
+    import torch
+    from conftest import GOLDEN_DIR
+    from merlin_amd import preprocess as pp
+    names = sorted(os.path.basename(p)[:-4]
+                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'ppguo_*.npz')))
+    assert len(names) == 3
+    for name in names:
+        g = load_pp(name)
+        p = g['p']
+        hp = g['highpass'].astype(np.float64)
+        got = pp.deconvolve_lucyrichardson_guo(hp, p['decon_size'], p['decon_sigma'],
+                                               p['iterations'])
+        check_f64(got, g['deconvolved'])
+        assert np.array_equal(got, po.deconvolve_lucyrichardson_guo(
+            hp, p['decon_size'], p['decon_sigma'], p['iterations']))
+    g = load_pp('ppguo_synth')
+    task = pp.DeconvolutionPreprocessGuo()
+    assert task.parameters['decon_iterations'] == 2 and task.parameters['decon_filter_size'] == 9
+    stack = np.stack([g['image'], g['image'][::-1].copy()])[None]           # [1, 2, H, W]
+    out, hist = task.preprocess_device(torch.from_numpy(stack).to(gpu_device))
+    out = out.cpu().numpy()
+    check_u16(out[0, 0], g['output'])
+    assert np.array_equal(hist[0].cpu().numpy(), po.pixel_histogram(out[0]).astype(np.int64))
+    with pytest.raises(NotImplementedError):
+        pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 15, 2, 2)
+    with pytest.raises(NotImplementedError):
+        pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 8, 2, 2)

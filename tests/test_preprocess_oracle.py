@@ -85,3 +85,31 @@ def test_blur_known_answers():
     s[:, 0] = 60000
     b = po.gaussian_blur_u16_replicate(s, 13, 3.0)
     assert b[8, 0] > b[8, 1] > b[8, 6] > 0 and b[8, 7] == 0
+
+
+GUO_NAMES = sorted(os.path.basename(p)[:-4]
+                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'ppguo_*.npz')))
+
+
+@pytest.mark.parametrize('name', GUO_NAMES)
+def test_guo_variant_bit_exact(name):
+    g = load_pp(name)
+    p = g['p']
+    pf, pb = po.calculate_projectors(p['decon_size'], p['decon_sigma'])
+    np.testing.assert_allclose(pf, g['pf'], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(pb, g['pb'], rtol=1e-10, atol=1e-16)      # FFT builds differ
+    dec = po.deconvolve_lucyrichardson_guo(g['highpass'].astype(np.float64), p['decon_size'],
+                                           p['decon_sigma'], p['iterations'])
+    np.testing.assert_allclose(dec, g['deconvolved'], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(po.to_uint16(g['deconvolved']), g['output'])
+
+
+def test_product_projectors_match_golden():
+    from merlin_amd.preprocess import calculate_projectors, matlab_gauss2D
+    assert len(GUO_NAMES) == 3
+    for name in GUO_NAMES:
+        g = load_pp(name)
+        pf, pb = calculate_projectors(g['p']['decon_size'], g['p']['decon_sigma'])
+        np.testing.assert_allclose(pf, g['pf'], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(pb, g['pb'], rtol=1e-10, atol=1e-16)
+    assert abs(matlab_gauss2D((9, 9), 2.0).sum() - 1.0) < 1e-15
