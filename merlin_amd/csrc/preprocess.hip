@@ -319,7 +319,7 @@ template <int R, int SEGT, int P, typename WT>
 __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 {
     constexpr int OUTW = TW - 4 * R;
-    constexpr int NRING = 2 * R + 1;
+    constexpr int NRING = R > 0 ? 2 * R : 1;   // rows parked between blur input and epilogue
     __shared__ double srow1[TW + 2 * R];
     __shared__ double srow2[TW + 2 * R];
     __shared__ double sj1[NRING][TW];
@@ -382,13 +382,18 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
             // ---- stage 1: reblurred row r - R, ratio ----
             lds_wave_order();
             srow1[R + lane] = y;
-            sj1[slot][lane] = y;
-            sj2[slot][lane] = told;
+            // the row parked 2R iterations ago is the output row's; its slot
+            // takes this row's values
+            double yo = y, to = told;
+            if constexpr (R > 0) {
+                yo = sj1[slot][lane];
+                to = sj2[slot][lane];
+                lds_wave_order();
+                sj1[slot][lane] = y;
+                sj2[slot][lane] = told;
+                slot = slot + 1 == NRING ? 0 : slot + 1;
+            }
             lds_wave_order();
-            // the row written 2R iterations ago is the output row's
-            const int oslot = slot + 1 == NRING ? 0 : slot + 1;
-            const double yo = sj1[oslot][lane], to = sj2[oslot][lane];
-            slot = oslot;
             double s1 = a.tp.k[0] * srow1[lane];
 #pragma unroll
             for (int j = 1; j <= 2 * R; ++j) s1 = s1 + a.tp.k[j] * srow1[lane + j];
