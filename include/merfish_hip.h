@@ -42,6 +42,9 @@ extern "C" {
 #define MF_HIST_BINS 65534   /* bins of np.arange(0, 65535), preprocess.py:114 */
 
 #define MF_CODEBOOK_UNIFORM 1 /* flag: all codewords share weight and value   */
+#define MF_CODEBOOK_MINHD_SHIFT   8  /* flags bits 8-15: minimum Hamming distance
+                                        of a uniform codebook (0 = not computed) */
+#define MF_CODEBOOK_WEIGHT_SHIFT 16  /* flags bits 16-23: its codeword weight    */
 
 #define MF_DECODE_TRACES_DECODED_ONLY 1 /* mf_decode_pixels flag, see there   */
 

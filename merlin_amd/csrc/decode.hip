@@ -69,7 +69,7 @@ constexpr int32_t CB_MAGIC = 0x4d464342;   // "MFCB"
 struct DecodeArgs {
     const void *img;
     int64_t bit_stride, z_stride;
-    int B, Z, H, W, N, Npad, fast_ok, uniform, fast_div;
+    int B, Z, H, W, N, Npad, fast_ok, uniform, fast_div, exclusive;
     const unsigned char *cbt;          // codebook table blob
     int64_t off_a, off_mask, off_v, off_hn, off_v64;
     float sf[MF_MAX_BITS], bg[MF_MAX_BITS];
@@ -129,8 +129,15 @@ __device__ __forceinline__ float fmin3(float a, float b, float c)
     return r;
 }
 
+// EXCL: the codebook and the threshold guarantee that no pixel has two
+// codewords within reach (see codebook_exclusive): the runner-up is not needed.
+template <bool EXCL>
 __device__ __forceinline__ void top2_update4(Top2 &t, float k1, float k2, float k3, float k4)
 {
+    if constexpr (EXCL) {
+        t.best = fmin3(fmin3(t.best, k1, k2), k3, k4);
+        return;
+    }
     const float m1 = __builtin_amdgcn_fmed3f(t.best, k1, k2);
     const float b1 = fmin3(t.best, k1, k2);
     const float m2 = __builtin_amdgcn_fmed3f(b1, k3, k4);
@@ -177,7 +184,7 @@ __device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask
 
 // FULL: B == MAXB and the reciprocal division applies, both known at compile
 // time (the common 16-bit / 32-bit codebooks): no per-bit guards.
-template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL>
+template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, bool EXCL>
 __global__ void __launch_bounds__(NTHREADS, MF_WAVES_PER_SIMD)
 decode_kernel(const DecodeArgs a)
 {
@@ -518,7 +525,7 @@ decode_kernel(const DecodeArgs a)
                                 s4[2] = fmaf(vv.z, acc[tt][4 * gq + 2], hh.z);
                                 s4[3] = fmaf(vv.w, acc[tt][4 * gq + 3], hh.w);
                             }
-                            top2_update4(st[tt], score_key(s4[0], 4 * gq + 0),
+                            top2_update4<EXCL>(st[tt], score_key(s4[0], 4 * gq + 0),
                                          score_key(s4[1], 4 * gq + 1), score_key(s4[2], 4 * gq + 2),
                                          score_key(s4[3], 4 * gq + 3));
                         }
@@ -531,8 +538,10 @@ decode_kernel(const DecodeArgs a)
             // after the swaps both states in a lane belong to its own pixel
             auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].best),
                                                        __float_as_uint(st[1].best), false, false);
-            auto ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].second),
-                                                       __float_as_uint(st[1].second), false, false);
+            auto ss = sb;
+            if constexpr (!EXCL)
+                ss = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[0].second),
+                                                      __float_as_uint(st[1].second), false, false);
             auto si = __builtin_amdgcn_permlane32_swap((unsigned)st[0].tile, (unsigned)st[1].tile,
                                                        false, false);
             // [0] came from the lane holding codeword rows 0-3 of every group of
@@ -541,7 +550,8 @@ decode_kernel(const DecodeArgs a)
             const float s0 = __uint_as_float(ss[0]), s1 = __uint_as_float(ss[1]);
             const bool from1 = b1 < b0;
             const float kbest = from1 ? b1 : b0;
-            const float ksecond = fmin3(from1 ? b0 : b1, s0, s1);
+            // EXCL: no runner-up, so the tie test below never fires
+            const float ksecond = EXCL ? KEY_INIT : fmin3(from1 ? b0 : b1, s0, s1);
             const int slot = __float_as_int(kbest) & KEY_SLOT_MASK;
             int win = (from1 ? (int)si[1] + 4 : (int)si[0]) + (slot & 3) + 8 * (slot >> 2);
             const float best = __int_as_float(__float_as_int(kbest) & ~KEY_SLOT_MASK);
@@ -606,7 +616,7 @@ decode_kernel(const DecodeArgs a)
     }
 }
 
-template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL>
+template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, bool EXCL>
 int launch(DecodeArgs &a, hipStream_t stream)
 {
     using HT = typename HType<PIX>::type;
@@ -642,7 +652,7 @@ int launch(DecodeArgs &a, hipStream_t stream)
     if (grid > nt) grid = nt;
     grid = (grid + 7) & ~int64_t(7);
 
-    auto kern = decode_kernel<PIX, R, MAXB, PPT, UNI, FULL>;
+    auto kern = decode_kernel<PIX, R, MAXB, PPT, UNI, FULL, EXCL>;
     if (lds > 48 * 1024)
         MF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -665,11 +675,12 @@ int dispatch_kind(DecodeArgs &a, hipStream_t s)
 {
     if constexpr (USE_FULL) {
         if (a.B == MAXB && a.fast_div)
-            return a.uniform ? launch<PIX, R, MAXB, PPT, true, true>(a, s)
-                             : launch<PIX, R, MAXB, PPT, false, true>(a, s);
+            return a.uniform ? launch<PIX, R, MAXB, PPT, true, true, false>(a, s)
+                             : launch<PIX, R, MAXB, PPT, false, true, false>(a, s);
     }
-    return a.uniform ? launch<PIX, R, MAXB, PPT, true, false>(a, s)
-                     : launch<PIX, R, MAXB, PPT, false, false>(a, s);
+    if (a.uniform && a.exclusive) return launch<PIX, R, MAXB, PPT, true, false, true>(a, s);
+    return a.uniform ? launch<PIX, R, MAXB, PPT, true, false, false>(a, s)
+                     : launch<PIX, R, MAXB, PPT, false, false, false>(a, s);
 }
 
 template <typename PIX, int R>
@@ -699,6 +710,28 @@ int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// Can two codewords of a uniform codebook (weight w, all values 1/sqrt(w),
+// minimum Hamming distance hd) both lie within `thr` of one unit vector?  Two
+// codewords share at most w - hd/2 on-bits: cos(theta) <= 1 - hd / (2 w).  A
+// unit trace x at distance d1 <= thr of c1 has x.c1 = a1 >= 1 - thr^2 / 2 and
+// then x.c2 <= cos(theta - acos(a1)).  If a1 exceeds that by more than the
+// float32 keys can blur (slot bits 2^-19 of a key, accumulation rounding:
+// < 5e-6 in these units; 2e-5 asked for), the float-key winner IS the exact
+// winner for every pixel that can decode, and the kernel needs no runner-up.
+// MHD4 (w = 4, hd = 4): margin 3.9e-5 at thr = 0.5176, 9.7e-4 at 0.5167; the two
+// meet at thr = sqrt(2 - sqrt 3) = 0.51764, which is where 0.5176 comes from.
+bool codebook_exclusive(int weight, int min_hd, double thr)
+{
+    if (weight < 1 || min_hd < 2 || !(thr >= 0)) return false;
+    const double a1 = 1.0 - 0.5 * thr * thr;
+    if (a1 <= 0.0) return false;
+    const double cos_theta = 1.0 - (double)min_hd / (2.0 * weight);
+    const double theta = std::acos(cos_theta < -1.0 ? -1.0 : cos_theta);
+    const double phi = std::acos(a1 > 1.0 ? 1.0 : a1);
+    if (phi >= 0.5 * theta) return false;
+    return a1 - std::cos(theta - phi) >= 2.0e-5;
+}
 
 void table_layout(int N, int B, CbHeader &h)
 {
@@ -784,13 +817,26 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
             uniform = 0;
     }
     h.uniform = uniform;
+    // minimum Hamming distance of a uniform codebook (for codebook_exclusive);
+    // quadratic, so only up to 4096 codewords
+    int min_hd = 0;
+    if (uniform && N >= 2 && N <= 4096) {
+        min_hd = 255;
+        for (int i = 0; i < N && min_hd > 0; ++i)
+            for (int j = i + 1; j < N; ++j) {
+                const int d = __builtin_popcount(mask[i] ^ mask[j]);
+                if (d < min_hd) min_hd = d;
+            }
+    }
     // a uniform key (-t * sum) is t / v = t * sqrt(weight) times the score
     h.key_c = 0.0f;
     h.key_scale =
         (float)((h.KB == 16 ? 1.0 : 0.5) * std::sqrt((double)__builtin_popcount(mask[0])));
     std::memcpy(blob.data(), &h, sizeof(h));
     MF_HIP_CHECK(hipMemcpy(table, blob.data(), (size_t)h.total, hipMemcpyHostToDevice));
-    return uniform ? MF_CODEBOOK_UNIFORM : 0;
+    return uniform ? (MF_CODEBOOK_UNIFORM | (min_hd << MF_CODEBOOK_MINHD_SHIFT) |
+                      (__builtin_popcount(mask[0]) << MF_CODEBOOK_WEIGHT_SHIFT))
+                   : 0;
 }
 
 extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, float *h_float)
@@ -878,6 +924,10 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     a.z_stride = img_z_stride;
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.N = N; a.Npad = h.Npad;
     a.uniform = (codebook_flags & MF_CODEBOOK_UNIFORM) != 0;
+    a.exclusive = a.uniform && std::getenv("MF_NO_EXCLUSIVE") == nullptr &&
+                  codebook_exclusive((codebook_flags >> MF_CODEBOOK_WEIGHT_SHIFT) & 0xff,
+                                     (codebook_flags >> MF_CODEBOOK_MINHD_SHIFT) & 0xff,
+                                     distance_threshold);
     // the 4-byte window loads need even element offsets for u16 rows
     a.fast_ok = image_dtype == MF_DTYPE_F32 ||
                 (!(W & 1) && !((img_bit_stride | img_z_stride) & 1) &&

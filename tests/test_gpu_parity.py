@@ -14,7 +14,7 @@ import pytest
 
 import merfish_oracle as oracle
 from conftest import (ArrayCodebook, AffineAligner, frame_to_array,
-                      golden_names, load_golden)
+                      golden_names, load_golden, synth_stack)
 
 pytestmark = pytest.mark.gpu
 
@@ -287,3 +287,34 @@ def test_argument_errors(gpu_device):
         PixelBasedDecoder(ArrayCodebook(bad), device=gpu_device).decode_pixels(img)
     with pytest.raises(NotImplementedError):
         PixelBasedDecoder(ArrayCodebook(np.ones((3, 40), dtype=int)))
+
+
+def test_exclusive_codebook_path_matches_runner_up_path(gpu_device, monkeypatch):
+    """MHD4 codebook + threshold <= 0.5176: the kernel drops the runner-up
+    (no two codewords can both be within reach, decode.hip codebook_exclusive).
+    Same decoded image and magnitudes as the top-2 path; distances identical
+    wherever a pixel decodes and within the documented 2e-6 elsewhere."""
+    import torch
+    from merlin_amd import _lib
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    dec._codebook_device()
+    flags = dec._cb_flags
+    assert flags & 1 and (flags >> 8) & 0xff == 4 and (flags >> 16) & 0xff == 4
+    img = torch.from_numpy(synth_stack(cb, (2, 384, 512), 900, seed=77)).to(gpu_device)
+    rng = np.random.default_rng(1)
+    sf = rng.uniform(300, 600, 16)
+    bg = np.zeros(16)
+    for thr in (0.5176, 0.5167, 0.3):
+        monkeypatch.delenv('MF_NO_EXCLUSIVE', raising=False)
+        a = dec.decode_pixels_device(img, sf, bg, thr, 1, 1)
+        monkeypatch.setenv('MF_NO_EXCLUSIVE', '1')
+        b = dec.decode_pixels_device(img, sf, bg, thr, 1, 1)
+        monkeypatch.delenv('MF_NO_EXCLUSIVE', raising=False)
+        da, db = a.decoded.cpu().numpy(), b.decoded.cpu().numpy()
+        assert np.array_equal(da, db) and (da >= 0).sum() > 1000
+        assert torch.equal(a.magnitudes, b.magnitudes)
+        xa, xb = a.distances.cpu().numpy(), b.distances.cpu().numpy()
+        assert np.array_equal(xa[da >= 0], xb[da >= 0])
+        np.testing.assert_allclose(xa, xb, rtol=2e-6, atol=0)
