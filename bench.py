@@ -188,7 +188,7 @@ def main():
     # page-locked HOST memory, uploaded by the pinned multi-buffered pipeline
     # (Decode.run_fovs_from_host) one FOV ahead of the kernels ----
     host_line = None
-    if rank == 0 and not args.no_host_pipeline:
+    if rank == 0 and world == 1 and not args.no_host_pipeline:
         hosts = [f.cpu().pin_memory() for f in fovs]
         n_host = max(4, min(args.steps, 20))
         for _ in task.run_fovs_from_host((hosts[i % 2] for i in range(3)), sf, bg):
@@ -209,7 +209,7 @@ def main():
     # the headline number: high-pass + 20 float64 Lucy-Richardson iterations per
     # 2048 x 2048 camera frame (112 frames make one FOV) ----
     pre_line = None
-    if rank == 0 and not args.no_preprocess:
+    if rank == 0 and world == 1 and not args.no_preprocess:
         from merlin_amd.preprocess import DeconvolutionPreprocess
         n_frames = 28
         g = torch.Generator(device=dev).manual_seed(SEED)
