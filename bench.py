@@ -211,12 +211,12 @@ def main():
     pre_line = None
     if rank == 0 and world == 1 and not args.no_preprocess:
         from merlin_amd.preprocess import DeconvolutionPreprocess
-        n_frames = 28
+        n_frames = B * Z                          # one FOV's camera frames
         g = torch.Generator(device=dev).manual_seed(SEED)
-        frames = (2000 + fovs[0][:4].reshape(-1, H, W)[:n_frames].float()
-                  + 10 * torch.randn((n_frames, H, W), device=dev, generator=g)
+        frames = (2000 + fovs[0].float()
+                  + 10 * torch.randn(fovs[0].shape, device=dev, generator=g)
                   ).clamp_(0, 65535).to(torch.uint16)
-        pre = DeconvolutionPreprocess(device=dev, batch=n_frames)
+        pre = DeconvolutionPreprocess(device=dev)
         pre.preprocess_device(frames)
         torch.cuda.synchronize(dev)
         p0 = torch.cuda.Event(enable_timing=True)
@@ -234,7 +234,7 @@ def main():
                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                  'frac': pre_bytes / ms_frame / 1e6 / HBM_PEAK_GBS},
                     'note': 'camera frames (offset 2000 + the synthetic FOV) -> uint16 stack + '
-                            'pixel histogram; {} frames per launch'.format(n_frames)}
+                            'pixel histogram for the {} frames of one FOV'.format(n_frames)}
         del frames, pre
         torch.cuda.empty_cache()
 
