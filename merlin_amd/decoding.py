@@ -35,6 +35,33 @@ def normalize(x):
         return x
 
 
+def _row_norms(m: np.ndarray) -> np.ndarray:
+    """np.linalg.norm of every row of a float64 [n, B] matrix with the bits of
+    the per-row call the reference makes (decoding.py:329-331): norm() of a
+    float64 vector is sqrt(x.dot(x)), and a stacked [n,1,B] @ [n,B,1] matmul
+    runs that same BLAS dot once per row (tests/test_optimize_dist.py checks the
+    identity on this numpy)."""
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    if m.shape[0] == 0:
+        return np.zeros(0)
+    return np.sqrt(np.matmul(m[:, None, :], m[:, :, None])[:, 0, 0])
+
+
+def _sum_rows_by_code(ids: np.ndarray, rows: np.ndarray, count: int
+                      ) -> np.ndarray:
+    """out[ids[k]] += rows[k] for k in order (the reference's running sums per
+    barcode in region order, decoding.py:329-332, 366-370): one weighted
+    bincount over (code, bit) cells, which accumulates sequentially in input
+    order."""
+    bits = rows.shape[1]
+    if not len(ids):
+        return np.zeros((count, bits))
+    cell = (np.asarray(ids, dtype=np.intp)[:, None] * bits
+            + np.arange(bits, dtype=np.intp)[None, :]).ravel()
+    return np.bincount(cell, weights=np.ascontiguousarray(rows).ravel(),
+                       minlength=count * bits).reshape(count, bits)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -610,9 +637,8 @@ class PixelBasedDecoder(object):
             # decoding.py:342-377, area threshold 5 hard-coded at :362
             sel = area >= 5
             seenBg = np.bincount(ids[sel], minlength=N).astype(np.float64)
-            sumMin = np.zeros((N, B))
-            np.add.at(sumMin, ids[sel],
-                      table.min_tm[rows][sel].astype(np.float64))
+            sumMin = _sum_rows_by_code(
+                ids[sel], table.min_tm[rows][sel].astype(np.float64), N)
             off = sumMin.copy()
             off[self._decodingMatrix > 0] = np.nan
             with np.errstate(invalid='ignore', divide='ignore'):
@@ -627,11 +653,9 @@ class PixelBasedDecoder(object):
         mean = table.mean_tm[rows][sel].astype(np.float64) \
             - backgroundRefactors
         with np.errstate(invalid='ignore', divide='ignore'):
-            norm = np.array([np.linalg.norm(v) for v in mean]) \
-                if len(mean) else np.zeros(0)
+            norm = _row_norms(mean)
             contrib = (mean / norm[:, None]) / barcodesSeen[ids[sel]][:, None]
-        sumPixelTraces = np.zeros((N, B))
-        np.add.at(sumPixelTraces, ids[sel], contrib)   # region order per code
+        sumPixelTraces = _sum_rows_by_code(ids[sel], contrib, N)
         sumPixelTraces[self._decodingMatrix == 0] = np.nan
         import warnings
         with warnings.catch_warnings():

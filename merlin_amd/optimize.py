@@ -164,7 +164,9 @@ class OptimizeIteration(object):
         if self._provider is None:
             raise ValueError('imageProvider is required')
         img = self._provider(fovIndex, zIndex)
-        vol = decoder.decode_pixels_device(img, scaleFactors, backgrounds)
+        # region statistics read the traces of decoded pixels only
+        vol = decoder.decode_pixels_device(img, scaleFactors, backgrounds,
+                                           returnTraces='decoded')
         out = decoder.extract_refactors_device(
             vol, self.parameters['optimize_background'])
         self._last_volume = vol
