@@ -159,6 +159,14 @@ __device__ __forceinline__ float div_by_recip(float n, float d, float r)
     return q;
 }
 
+// A/B switches of dev/mkvariant.sh (both on by default)
+#ifndef MF_VPASS_F64
+#define MF_VPASS_F64 1
+#endif
+#ifndef MF_D2_FMA
+#define MF_D2_FMA 1
+#endif
+
 // exact float64 squared distance between the normalised trace and codeword
 // (mask, v): sum_b (x_b - c_b)^2 in bit order (sklearn's rdist loop)
 template <int MAXB>
@@ -168,8 +176,14 @@ __device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask
 #pragma unroll
     for (int b = 0; b < MAXB; ++b)
         if (b < B) {
+#if MF_D2_FMA
+            // x - c with c = v * bit (bit is 0 or 1, so the product is exact
+            // and the fused result is the rounded difference)
+            const double t = __builtin_fma(-(double)((mask >> b) & 1u), v, (double)x[b]);
+#else
             const double c = (mask >> b) & 1u ? v : 0.0;
             const double t = (double)x[b] - c;
+#endif
             d2 = d2 + t * t;
         }
     return d2;
@@ -261,6 +275,9 @@ decode_kernel(const DecodeArgs a)
 
         float x[PPT][MAXB];
         uint32_t win[NTASK][WDW];
+        double kd[2 * R + 1];
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) kd[j] = (double)a.kfix[j];
 
         // ---- global -> register windows for one group of bits ----
         auto prefetch = [&](int g) {
@@ -361,10 +378,25 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                     for (int j = 0; j < PPT + 2 * R; ++j)
                         col[j] = hs[(i * RH + wave * PPT + j) * TW + lane];
+                    double cd[PPT + 2 * R];
+                    if constexpr (IS_U16 && MF_VPASS_F64) {
+#pragma unroll
+                        for (int j = 0; j < PPT + 2 * R; ++j) cd[j] = (double)col[j];
+                    }
 #pragma unroll
                     for (int o = 0; o < PPT; ++o) {
                         float v;
-                        if constexpr (IS_U16) {
+                        if constexpr (IS_U16 && MF_VPASS_F64) {
+                            // V = sum k_j * H_j < 2^48 is exact in float64 (H < 2^32,
+                            // pair sums < 2^33, taps < 2^16); V * 2^-32 + 0.5 is exact
+                            // too (an integer multiple of 2^-32 below 2^17), so the
+                            // truncating conversion is (V + 2^31) >> 32
+                            double acc = kd[R] * cd[o + R];
+#pragma unroll
+                            for (int j = 1; j <= R; ++j)
+                                acc = __builtin_fma(kd[R + j], cd[o + R - j] + cd[o + R + j], acc);
+                            v = (float)(uint32_t)__builtin_fma(acc, 0x1p-32, 0.5);
+                        } else if constexpr (IS_U16) {
                             // V = sum k_j * H_j needs 48 bits: split H into 16-bit
                             // halves, two exact u32 sums, out = (V + 2^31) >> 32
                             // (operands < 2^24: full-rate 24-bit multiplies)
