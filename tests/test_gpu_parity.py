@@ -318,3 +318,31 @@ def test_exclusive_codebook_path_matches_runner_up_path(gpu_device, monkeypatch)
         xa, xb = a.distances.cpu().numpy(), b.distances.cpu().numpy()
         assert np.array_equal(xa[da >= 0], xb[da >= 0])
         np.testing.assert_allclose(xa, xb, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize('spots', [0, 3])
+def test_extract_refactors_with_few_or_no_regions(spots, gpu_device):
+    """A plane in which nothing (or nearly nothing) decodes: barcodes that were
+    never seen leave 0/0 = NaN exactly where the reference's loop does
+    (decoding.py:329-340), with and without the background term."""
+    g = load_golden('g2_synth192')
+    cb = g['codebook']
+    img = synth_stack(cb, (1, 64, 96), spots, seed=77)[:, 0]
+    if spots == 0:
+        img[:] = 0
+    sf, bg = np.full(16, 300.0), np.zeros(16)
+    dm = oracle.normalized_codebook(cb)
+    di, pm, npt, d = oracle.decode_pixels(img, dm, sf, bg, 0.5176, 1, 1)
+    from merlin_amd.decoding import PixelBasedDecoder
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    gdi, gpm, gnpt, gd = dec.decode_pixels(img, sf, bg)
+    assert np.array_equal(gdi, di) and np.array_equal(gpm, pm)
+    if spots == 0:
+        assert (gdi == -1).all()
+    for with_bg in (False, True):
+        with np.errstate(all='ignore'):
+            want = oracle.extract_refactors(di, pm, npt, dm, 4, with_bg)
+            got = dec.extract_refactors(gdi, gpm, gnpt, with_bg)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=1e-12, equal_nan=True)
+            assert np.array_equal(np.isnan(a), np.isnan(b))
