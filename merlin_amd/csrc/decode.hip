@@ -159,7 +159,21 @@ __device__ __forceinline__ float div_by_recip(float n, float d, float r)
     return q;
 }
 
-// A/B switches of dev/mkvariant.sh (both on by default)
+// Two quotients per instruction (v_pk_mul_f32 / v_pk_fma_f32): the same five
+// roundings per element as div_by_recip.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 div_by_recip2(f32x2 n, f32x2 d, f32x2 r)
+{
+    f32x2 q = n * r;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, d, n), r, q);
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, d, n), r, q);
+    return q;
+}
+
+// A/B switches of dev/mkvariant.sh (all on by default)
+#ifndef MF_PK_F32
+#define MF_PK_F32 1
+#endif
 #ifndef MF_VPASS_F64
 #define MF_VPASS_F64 1
 #endif
@@ -417,8 +431,25 @@ decode_kernel(const DecodeArgs a)
                                 acc = acc + a.kflt[R + j] * (col[o + R - j] + col[o + R + j]);
                             v = acc;
                         }
-                        x[o][b] = b >= B ? 0.0f : fast_div ? div_by_recip(v - bgb, sfb, rsb)
-                                                            : (v - bgb) / sfb;
+                        if constexpr (MF_PK_F32 && PPT % 2 == 0)
+                            x[o][b] = v;
+                        else
+                            x[o][b] = b >= B ? 0.0f : fast_div ? div_by_recip(v - bgb, sfb, rsb)
+                                                                : (v - bgb) / sfb;
+                    }
+                    if constexpr (MF_PK_F32 && PPT % 2 == 0) {
+                        // pixel rows in pairs: one packed instruction per two quotients
+#pragma unroll
+                        for (int o = 0; o < PPT; o += 2) {
+                            f32x2 n = {x[o][b], x[o + 1][b]};
+                            n = n - (f32x2){bgb, bgb};
+                            if (fast_div)
+                                n = div_by_recip2(n, (f32x2){sfb, sfb}, (f32x2){rsb, rsb});
+                            else
+                                n = n / (f32x2){sfb, sfb};
+                            x[o][b] = b >= B ? 0.0f : n.x;
+                            x[o + 1][b] = b >= B ? 0.0f : n.y;
+                        }
                     }
                 }
                 __syncthreads();   // hs is rewritten by the next group
@@ -432,6 +463,39 @@ decode_kernel(const DecodeArgs a)
 
         // ---- magnitude and L2 normalisation (decoding.py:106-110) ----
         float mag[PPT];
+        if constexpr (MF_PK_F32 && PPT % 2 == 0) {
+#pragma unroll
+            for (int o = 0; o < PPT; o += 2) {
+                f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) {
+                    const f32x2 xx = {x[o][b], x[o + 1][b]};
+                    acc = acc + xx * xx;               // unfused, in bit order
+                }
+                f32x2 m = {sqrtf(acc.x), sqrtf(acc.y)};
+                if (m.x == 0.0f) m.x = 1.0f;
+                if (m.y == 0.0f) m.y = 1.0f;
+                mag[o] = m.x;
+                mag[o + 1] = m.y;
+#ifndef MF_ABL_NONORM
+                if (fast_div && fminf(m.x, m.y) > 0x1p-60f && fmaxf(m.x, m.y) < 0x1p60f) {
+                    const f32x2 rm = {1.0f / m.x, 1.0f / m.y};
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) {
+                        const f32x2 q = div_by_recip2((f32x2){x[o][b], x[o + 1][b]}, m, rm);
+                        x[o][b] = q.x;
+                        x[o + 1][b] = q.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) {
+                        x[o][b] = x[o][b] / m.x;
+                        x[o + 1][b] = x[o + 1][b] / m.y;
+                    }
+                }
+#endif
+            }
+        } else
 #pragma unroll
         for (int o = 0; o < PPT; ++o) {
             float acc = 0.0f;
