@@ -77,7 +77,17 @@ class Decode(object):
 
     def _enqueue_decode(self, imageStack, scaleFactors, backgrounds):
         """Stage 1 of a FOV: decode kernel + labelling, nothing blocks."""
+        timing = getattr(self, 'kernel_events', None)
+        if timing is not None:
+            # measurement hook (bench.py): HIP events around the decode launch
+            # on the stream it is queued on
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         vol = self.decode_fov_device(imageStack, scaleFactors, backgrounds)
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1))
         lab = self.decoder._label_enqueue(vol, bool(self.parameters['decode_3d']))
         return vol, lab
 
