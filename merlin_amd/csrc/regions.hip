@@ -828,8 +828,14 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
     MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), sel,
                                  reinterpret_cast<unsigned long long *>(d_count),
                                  (size_t)n_regions, keep, s));
+    // rows written over PCIe into mapped host memory: few workgroups, so the
+    // decode kernel of the next FOV keeps its CUs; into device memory: a full grid
     unsigned g = (unsigned)((n_regions + GATHER_NT - 1) / GATHER_NT);
-    if (g > 4u) g = 4u;
+    hipPointerAttribute_t at;
+    const bool to_device = hipPointerGetAttributes(&at, out64) == hipSuccess &&
+                           at.type == hipMemoryTypeDevice;
+    const unsigned g_max = to_device ? 512u : 4u;
+    if (g > g_max) g = g_max;
     if (const char *e = std::getenv("MF_GATHER_WGS")) g = (unsigned)std::atoi(e);   // tuning aid
     hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel, gidx,
                        reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,

@@ -15,6 +15,8 @@ Beyond the reference API the class offers device-resident variants
 import weakref
 from typing import Optional, Tuple
 
+import os
+
 import numpy as np
 import pandas
 import torch
@@ -60,6 +62,13 @@ def _sum_rows_by_code(ids: np.ndarray, rows: np.ndarray, count: int
             + np.arange(bits, dtype=np.intp)[None, :]).ravel()
     return np.bincount(cell, weights=np.ascontiguousarray(rows).ravel(),
                        minlength=count * bits).reshape(count, bits)
+
+
+# Frame rows are staged in HBM and moved to the host by the copy engine;
+# MF_FRAME_DIRECT=1 (A/B switch) has the gather kernel write them over PCIe
+# instead, which costs the next FOV's decode kernel 5 % (its tiles are statically
+# spread over the CUs the gather's workgroups sit on).
+_FRAME_VIA_COPY = not os.environ.get('MF_FRAME_DIRECT')
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -507,7 +516,8 @@ class PixelBasedDecoder(object):
                        minimumArea, cropShape, stream=None):
         """Launch mf_region_frame for every row of a device-resident table:
         the crop / area filter and the column gather run on the GPU, which
-        writes only the kept rows, column-major, into page-locked buffers.
+        writes only the kept rows, column-major; three asynchronous copies
+        bring them into page-locked buffers.
         Returns the pending state for _frame_finish.  With ``stream`` the work
         runs on that side stream (after what the current stream has queued),
         so it overlaps whatever the caller launches next."""
@@ -528,14 +538,26 @@ class PixelBasedDecoder(object):
             with torch.cuda.stream(run):
                 ws_bytes = _lib.check(L.mf_region_frame_workspace_bytes(n))
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                # the kernels write the kept rows straight into the pinned
-                # buffers
+                if _FRAME_VIA_COPY:
+                    # rows into device buffers, then the copy engine moves
+                    # them: no workgroup sits on PCIe beside the next decode
+                    o64 = torch.empty_like(h64, device=dev)
+                    o32 = torch.empty_like(h32, device=dev)
+                    ocount = torch.empty_like(hcount, device=dev)
+                else:
+                    o64, o32, ocount = h64, h32, hcount
                 _lib.check(L.mf_region_frame(
                     rec.data_ptr(), table.inten_d.data_ptr(), n, bitCount,
                     int(is3D), float(cropWidth), float(cropShape[0]),
-                    float(cropShape[1]), float(minimumArea), h64.data_ptr(),
-                    h32.data_ptr(), hcount.data_ptr(), ws.data_ptr(),
+                    float(cropShape[1]), float(minimumArea), o64.data_ptr(),
+                    o32.data_ptr(), ocount.data_ptr(), ws.data_ptr(),
                     ws_bytes, run.cuda_stream))
+                if _FRAME_VIA_COPY:
+                    hcount.copy_(ocount, non_blocking=True)
+                    h64.copy_(o64, non_blocking=True)
+                    h32.copy_(o32, non_blocking=True)
+                    for t in (o64, o32, ocount):
+                        t.record_stream(run)
                 done = torch.cuda.Event()
                 done.record(run)
         # `table` and `ws` stay referenced until the event has fired
