@@ -66,8 +66,8 @@ def _sum_rows_by_code(ids: np.ndarray, rows: np.ndarray, count: int
 
 # Frame rows are staged in HBM and moved to the host by the copy engine;
 # MF_FRAME_DIRECT=1 (A/B switch) has the gather kernel write them over PCIe
-# instead, which costs the next FOV's decode kernel 5 % (its tiles are statically
-# spread over the CUs the gather's workgroups sit on).
+# instead, which costs the next FOV's decode kernel 5 % (measured; more with more
+# workgroups storing into mapped host memory).
 _FRAME_VIA_COPY = not os.environ.get('MF_FRAME_DIRECT')
 
 
