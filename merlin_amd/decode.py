@@ -47,6 +47,18 @@ class Decode(object):
                 self._side = torch.cuda.Stream(dev)
         return self._side
 
+    def _table_stream(self, dev):
+        """Second compute stream for the region-table stage of the pipelined
+        FOV loop (MF_NO_TABLE_STREAM=1: tuning aid, everything on one stream)."""
+        import os
+        if os.environ.get('MF_NO_TABLE_STREAM'):
+            return None
+        if getattr(self, '_tbl', None) is None:
+            with torch.cuda.device(dev):
+                self._tbl = torch.cuda.Stream(
+                    dev, priority=int(os.environ.get('MF_TABLE_PRIORITY', '0')))
+        return self._tbl
+
     def decode_fov_device(self, imageStack: torch.Tensor, scaleFactors,
                           backgrounds, returnTraces='decoded'
                           ) -> DecodedVolume:
@@ -96,11 +108,28 @@ class Decode(object):
         region counts that size the tables."""
         p = self.parameters
         is3D = bool(p['decode_3d'])
-        table = self.decoder.region_table(vol, is3D, pendingLabels=lab)
         Z, H, W = vol.shape
-        return self.decoder._frame_enqueue(
-            table, is3D, vol.bit_count, self.cropWidth, p['minimum_area'],
-            (Z, H, W) if is3D else (H, W), stream=side)
+        shape = (Z, H, W) if is3D else (H, W)
+        tbl = self._table_stream(vol.decoded.device) if side is not None \
+            else None
+        if tbl is None:
+            table = self.decoder.region_table(vol, is3D, pendingLabels=lab)
+            return self.decoder._frame_enqueue(
+                table, is3D, vol.bit_count, self.cropWidth,
+                p['minimum_area'], shape, stream=side)
+        # the sort / region statistics of this FOV on their own stream, beside
+        # the decode kernel of the next FOV (already queued on the main one)
+        tbl.wait_event(lab[3])
+        with torch.cuda.stream(tbl):
+            table = self.decoder.region_table(vol, is3D, pendingLabels=lab)
+            pending = self.decoder._frame_enqueue(
+                table, is3D, vol.bit_count, self.cropWidth,
+                p['minimum_area'], shape, stream=side)
+        for t in (vol.decoded, vol.magnitudes, vol.distances, vol.traces,
+                  lab[0]):
+            if t is not None:
+                t.record_stream(tbl)
+        return pending
 
     def run_fov(self, imageStack: torch.Tensor, scaleFactors, backgrounds,
                 fov: int, globalAligner=None, zPositions=None):
