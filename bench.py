@@ -162,6 +162,20 @@ def main():
     # the two events of a pair ----
     px_fov = Z * H * W
     k_ms = sum(a.elapsed_time(b) for a, b in k_events) / max(len(k_events), 1)
+    # the same kernel with the GPU to itself (in the timed region it shares the
+    # CUs with the previous FOV's sort / region statistics on a second stream)
+    for r in range(12):
+        v = task.decode_fov_device(fovs[r % 2], sf, bg)
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(20):
+        v = task.decode_fov_device(fovs[r % 2], sf, bg)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    k_alone_ms = e0.elapsed_time(e1) / 20
+    del v
     # algorithmic bytes per pixel: 2B in (u16 stack) + 2 (int16 id) + 4
     # (magnitude) + 8 (float64 distance) = 2B + 14, plus 4B of normalised
     # traces for every decoded pixel (the FOV path keeps no others)
@@ -253,6 +267,12 @@ def main():
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'kernel_ms': k_ms, 'launches_timed': len(k_events),
+                'alone': {'kernel_ms': k_alone_ms,
+                          'achieved': alg_bytes / (k_alone_ms * 1e-3) / 1e9,
+                          'frac': alg_bytes / (k_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'note': 'same kernel back to back on an otherwise idle GPU; '
+                                  'in the timed region it overlaps the previous '
+                                  "FOV's region-table stage"},
                 'algorithmic_bytes': alg_bytes},
         }
         if host_line is not None:

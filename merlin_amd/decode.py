@@ -153,9 +153,10 @@ class Decode(object):
 
         Software pipeline, three FOVs in flight: the decode kernel and the
         labelling of FOV k+1 are queued before the host waits for FOV k's
-        region counts, so that wait costs the GPU nothing; FOV k's frame rows
-        cross PCIe on a side stream and FOV k-1's DataFrame is assembled on
-        the host meanwhile."""
+        region counts, so that wait costs the GPU nothing; FOV k's sort and
+        region statistics run on a second compute stream beside that decode
+        kernel, its frame rows cross PCIe on a third and FOV k-1's DataFrame
+        is assembled on the host meanwhile."""
         dev = self.decoder._dev()
         side = self._side_stream(dev)
         decoded = None      # (vol, labels pending, fov): stage 1 queued
