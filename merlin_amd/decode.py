@@ -7,6 +7,8 @@ the same products: the barcode table the task writes to the barcode database
 (decode.py:225-230) and the decoded / magnitude / distance images
 (decode.py:113-127).  Parameter names and defaults are the task's
 (decode.py:46-66)."""
+import os
+
 import numpy as np
 import torch
 
@@ -87,7 +89,7 @@ class Decode(object):
                 p['z_duplicate_xy_pixel_threshold'], zpos)
         return bc
 
-    def _enqueue_decode(self, imageStack, scaleFactors, backgrounds):
+    def _enqueue_decode(self, imageStack, scaleFactors, backgrounds, lbl=None):
         """Stage 1 of a FOV: decode kernel + labelling, nothing blocks."""
         timing = getattr(self, 'kernel_events', None)
         if timing is not None:
@@ -100,7 +102,16 @@ class Decode(object):
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
-        lab = self.decoder._label_enqueue(vol, bool(self.parameters['decode_3d']))
+        is3D = bool(self.parameters['decode_3d'])
+        if lbl is None:
+            lab = self.decoder._label_enqueue(vol, is3D)
+        else:
+            # the labelling on its own stream: the main one carries nothing
+            # but decode kernels
+            lbl.wait_stream(torch.cuda.current_stream(vol.decoded.device))
+            with torch.cuda.stream(lbl):
+                lab = self.decoder._label_enqueue(vol, is3D)
+            vol.decoded.record_stream(lbl)
         return vol, lab
 
     def _enqueue_table(self, vol, lab, side=None):
@@ -153,12 +164,20 @@ class Decode(object):
 
         Software pipeline, three FOVs in flight: the decode kernel and the
         labelling of FOV k+1 are queued before the host waits for FOV k's
-        region counts, so that wait costs the GPU nothing; FOV k's sort and
-        region statistics run on a second compute stream beside that decode
-        kernel, its frame rows cross PCIe on a third and FOV k-1's DataFrame
-        is assembled on the host meanwhile."""
+        region counts, so that wait costs the GPU nothing; the labelling and
+        the sort / region statistics of FOV k run on two more compute streams
+        beside that decode kernel, its frame rows cross PCIe on a copy stream
+        and FOV k-1's DataFrame is assembled on the host meanwhile
+        (MF_NO_LABEL_STREAM / MF_NO_TABLE_STREAM / MF_NO_SIDE: tuning aids)."""
         dev = self.decoder._dev()
         side = self._side_stream(dev)
+        lbl = None
+        if side is not None and self._table_stream(dev) is not None \
+                and not os.environ.get('MF_NO_LABEL_STREAM'):
+            if getattr(self, '_lbl', None) is None:
+                with torch.cuda.device(dev):
+                    self._lbl = torch.cuda.Stream(dev)
+            lbl = self._lbl
         decoded = None      # (vol, labels pending, fov): stage 1 queued
         tabled = None       # (vol, frame pending, fov): stage 2 queued
 
@@ -168,8 +187,8 @@ class Decode(object):
 
         for k, stack in enumerate(imageStacks):
             fov = k if fovs is None else fovs[k]
-            nxt = self._enqueue_decode(stack, scaleFactors, backgrounds) \
-                + (fov,)
+            nxt = self._enqueue_decode(stack, scaleFactors, backgrounds,
+                                       lbl) + (fov,)
             if decoded is not None:
                 pending = self._enqueue_table(decoded[0], decoded[1], side)
                 if tabled is not None:
