@@ -563,8 +563,8 @@ class PixelBasedDecoder(object):
         # `table` and `ws` stay referenced until the event has fired
         return (table, ws, h64, h32, hcount, done)
 
-    def _frame_finish(self, pending, bitCount, fov, globalAligner
-                      ) -> pandas.DataFrame:
+    def _frame_finish(self, pending, bitCount, fov, globalAligner,
+                      zOverride=None) -> pandas.DataFrame:
         """Wait for _frame_enqueue's rows and hand them to pandas without a
         copy.  globalAligner is applied to the kept rows (it is a per-row
         affine map, globalalign.py:141-148)."""
@@ -577,6 +577,10 @@ class PixelBasedDecoder(object):
         a64 = h64.numpy()[:, :m]
         a32 = h32.numpy()[:, :m]
         xs, ys, zs = a64[6], a64[7], a64[8]
+        if zOverride is not None:
+            # a single plane decoded on its own carries the caller's zIndex
+            # (decoding.py:209-211)
+            zs = np.full(m, float(zOverride))
         if globalAligner is not None:
             centroids = np.stack([zs, xs, ys], axis=1)
             g = np.asarray(globalAligner.fov_coordinate_array_to_global(
@@ -599,12 +603,13 @@ class PixelBasedDecoder(object):
                                 copy=False)
 
     def _frame_on_device(self, table: RegionTable, is3D, bitCount, fov,
-                         cropWidth, globalAligner, minimumArea, cropShape
-                         ) -> pandas.DataFrame:
+                         cropWidth, globalAligner, minimumArea, cropShape,
+                         zOverride=None) -> pandas.DataFrame:
         """_frame_from_rows for every row of a device-resident table."""
         pending = self._frame_enqueue(table, is3D, bitCount, cropWidth,
                                       minimumArea, cropShape)
-        return self._frame_finish(pending, bitCount, fov, globalAligner)
+        return self._frame_finish(pending, bitCount, fov, globalAligner,
+                                  zOverride)
 
     def extract_barcodes_with_index(
             self, barcodeIndex: int, decodedImage: np.ndarray,
@@ -642,6 +647,12 @@ class PixelBasedDecoder(object):
             return self._frame_on_device(
                 table, is3D, vol.bit_count, fov, cropWidth, globalAligner,
                 minimumArea, cropShape)
+        if Z == 1 and zPlane in (None, 0) and len(table):
+            # one plane decoded on its own (OptimizeIteration's fragments):
+            # every row, z = the caller's zIndex
+            return self._frame_on_device(
+                table, is3D, vol.bit_count, fov, cropWidth, globalAligner,
+                minimumArea, cropShape, zOverride=zIndex)
         rows = np.arange(len(table)) if zPlane is None \
             else np.nonzero(table.rec[:, 1] == zPlane)[0]
         return self._frame_from_rows(

@@ -170,6 +170,20 @@ def test_optimize_iterations_match_oracle(gpu_device):
             rf, bgr, seen = oracle.extract_refactors(di, pm, npt, dm, 3, True)
             rfs.append(rf)
             bgrs.append(bgr)
+            # the fragment's barcode table (optimize.py:116-122): crop 0,
+            # z = the fragment's z index, minimum area = area_threshold
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                exp = oracle.extract_all_barcodes(140, di, pm, npt, d, f, 0, z,
+                                                  None, 3)
+            got = cur.barcodes[frags.index([f, z])]
+            assert list(got.columns) == list(exp.columns) and len(exp) > 5
+            r, e = frame_to_array(got, 16), frame_to_array(exp, 16)
+            assert r.shape == e.shape
+            np.testing.assert_allclose(r[:, :14], e[:, :14], rtol=1e-12,
+                                       atol=1e-12)
+            assert np.array_equal(r[:, 14:], e[:, 14:])
+            assert np.array_equal(got.index.to_numpy(), exp.index.to_numpy())
         prevf = np.tile(sf, (2, 1))
         esf = oracle.reduce_scale_factors(np.array(rfs), prevf)
         ebg = oracle.reduce_backgrounds(np.array(bgrs), np.tile(bg, (2, 1)),
