@@ -664,6 +664,8 @@ class PixelBasedDecoder(object):
     def _refactors_from_table(self, table: RegionTable, rows,
                               extractBackgrounds: bool):
         N, B = self._barcodeCount, self._bitCount
+        if rows is None:                 # every row: no gather copies
+            rows = slice(None)
         ids = table.rec[rows, 0].astype(np.int64)
         area = table.rec[rows, 2]
         if extractBackgrounds:
@@ -706,12 +708,11 @@ class PixelBasedDecoder(object):
         vol = self._lookup(decodedImage, pixelMagnitudes,
                            normalizedPixelTraces, None)
         table = self.region_table(vol, False, True)
-        return self._refactors_from_table(table, np.arange(len(table)),
-                                          extractBackgrounds)
+        return self._refactors_from_table(table, None, extractBackgrounds)
 
     def extract_refactors_device(self, vol: DecodedVolume,
                                  extractBackgrounds=False, zPlane=None):
         table = self.region_table(vol, False, True)
-        rows = np.arange(len(table)) if zPlane is None \
+        rows = None if zPlane is None \
             else np.nonzero(table.rec[:, 1] == zPlane)[0]
         return self._refactors_from_table(table, rows, extractBackgrounds)
