@@ -175,9 +175,11 @@ int mf_region_table(const int16_t *decoded, const float *magnitudes,
  *          mean_distance, min_distance, x, y, z, index-in-group
  *   out32  f32 [B][n_regions]: the per-bit intensities, same convention
  *   count  int64 [1]: number of kept rows
- * out64 / out32 / count may be device memory or page-locked host memory that
- * is mapped into the device (hipHostMalloc): the kernels then write the rows
- * straight across PCIe.  Read them after the stream has been synchronised. */
+ * out64 / out32 / count may be device memory (a full grid writes the rows;
+ * copy them to the host afterwards) or page-locked host memory that is mapped
+ * into the device (hipHostMalloc): four workgroups then write the rows straight
+ * across PCIe, which slows kernels running beside them by about 5 %.  Read them
+ * after the stream has been synchronised. */
 int64_t mf_region_frame_workspace_bytes(int64_t n_regions);
 int mf_region_frame(const double *rec, const float *inten, int64_t n_regions,
                     int B, int conn3d, double crop_width, double crop_shape0,
