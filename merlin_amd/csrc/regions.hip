@@ -13,8 +13,6 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/device/device_select.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 
@@ -353,7 +351,7 @@ chunk_count(const int16_t *__restrict__ dec, const uint32_t *__restrict__ keys, 
 // 16-byte loads: the kernel is pure latency)
 constexpr int SCAN_NT = 1024;
 __global__ void __launch_bounds__(SCAN_NT)
-chunk_scan(int32_t *counts, int n_chunks)
+chunk_scan(int32_t *counts, int n_chunks, unsigned long long *total)
 {
     __shared__ int s_wave[SCAN_NT / 64];
     const int per = ((n_chunks + SCAN_NT - 1) / SCAN_NT + 3) & ~3;
@@ -390,6 +388,8 @@ chunk_scan(int32_t *counts, int n_chunks)
         counts[i] = run;
         run += c;
     }
+    // the last non-empty slice ends at the grand total
+    if (total && hi == n_chunks && lo < n_chunks) *total = (unsigned long long)run;
 }
 
 // assigned pixels in raster order with their component root as sort key
@@ -706,24 +706,53 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
 struct KeepRow {
     const double *rec;
     double lo, x_hi, y_hi, min_area;
-    __device__ bool operator()(int r) const
+    __device__ bool operator()(int64_t r) const
     {
-        const double *row = rec + (int64_t)r * MF_REC_COLS;
+        const double *row = rec + r * MF_REC_COLS;
         const double x = row[9], y = row[8];
         return x > lo && x < x_hi && y > lo && y < y_hi && row[2] >= min_area;
     }
 };
 
-// Position of every row inside its (z plane, barcode) group -- the DataFrame
+// Order-preserving selection of the kept rows with the same count / scan /
+// emit compaction the pixel lists use (no device-wide look-back chain).
+__device__ __forceinline__ unsigned keep_flags(const KeepRow &keep, int64_t i0, int64_t n)
+{
+    unsigned f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n && keep(i0 + k)) f |= 1u << k;
+    return f;
+}
+
+__global__ void __launch_bounds__(NT)
+keep_count(const KeepRow keep, int64_t n, int32_t *__restrict__ counts)
+{
+    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
+    const int total = block_reduce_sum(__popc(keep_flags(keep, i0, n)));
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(NT)
+keep_emit(const KeepRow keep, int64_t n, const int32_t *__restrict__ offsets,
+          int32_t *__restrict__ sel)
+{
+    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
+    const unsigned f = keep_flags(keep, i0, n);
+    int pos = offsets[blockIdx.x] + block_exclusive_scan(__popc(f));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (f >> k & 1u) sel[pos++] = (int32_t)(i0 + k);
+}
+
+// Position of a row inside its (z plane, barcode) group -- the DataFrame
 // index the reference ends up with, since it builds one frame per plane and
 // barcode (decoding.py:246-252, decode.py:225-230).  Rows are sorted by that
 // key: a binary search for the group's first row.  2-D key = (column 1,
 // column 0), 3-D key = column 0.
-__global__ void __launch_bounds__(NT)
-group_index(const double *__restrict__ rec, int64_t n, int conn3d, int32_t *__restrict__ idx)
+__device__ __forceinline__ int64_t group_index(const double *__restrict__ rec, int64_t r,
+                                               int conn3d)
 {
-    const int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (r >= n) return;
     const double kb = rec[r * MF_REC_COLS], kz = conn3d ? 0.0 : rec[r * MF_REC_COLS + 1];
     int64_t lo = 0, hi = r;
     while (lo < hi) {
@@ -731,20 +760,21 @@ group_index(const double *__restrict__ rec, int64_t n, int conn3d, int32_t *__re
         const double mb = rec[mid * MF_REC_COLS], mz = conn3d ? 0.0 : rec[mid * MF_REC_COLS + 1];
         if (mz < kz || (mz == kz && mb < kb)) lo = mid + 1; else hi = mid;
     }
-    idx[r] = (int32_t)(r - lo);
+    return r - lo;
 }
 
-// column-major gather of the kept rows; `count` was written by the select.
+// column-major gather of the kept rows; `count` was written by the scan.
 constexpr int GATHER_NT = 1024;
 
 __global__ void __launch_bounds__(GATHER_NT)
 frame_gather(const double *__restrict__ rec, const float *__restrict__ inten,
-             const int32_t *__restrict__ sel, const int32_t *__restrict__ gidx,
+             const int32_t *__restrict__ sel,
              const unsigned long long *__restrict__ count,
-             int64_t n_reg, int B, int zcol, double *__restrict__ out64,
+             int64_t n_reg, int B, int conn3d, double *__restrict__ out64,
              float *__restrict__ out32)
 {
     const int64_t m = (int64_t)*count;
+    const int zcol = conn3d ? 7 : 1;
     const int cols[MF_FRAME_COLS - 1] = {0, 3, 4, 2, 5, 6, 9, 8, zcol};
     for (int64_t i = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x; i < m;
          i += (int64_t)gridDim.x * GATHER_NT) {
@@ -752,7 +782,7 @@ frame_gather(const double *__restrict__ rec, const float *__restrict__ inten,
         const double *row = rec + r * MF_REC_COLS;
 #pragma unroll
         for (int c = 0; c < MF_FRAME_COLS - 1; ++c) out64[(int64_t)c * n_reg + i] = row[cols[c]];
-        out64[(int64_t)(MF_FRAME_COLS - 1) * n_reg + i] = (double)gidx[r];
+        out64[(int64_t)(MF_FRAME_COLS - 1) * n_reg + i] = (double)group_index(rec, r, conn3d);
         for (int b = 0; b < B; ++b) out32[(int64_t)b * n_reg + i] = inten[r * B + b];
     }
 }
@@ -771,18 +801,66 @@ int device_view(T *p, T **out, const char *what)
     return MF_OK;
 }
 
+// scratch of mf_region_frame: the kept rows' indexes and the chunk counts
+inline size_t frame_scratch_bytes(int64_t n_regions)
+{
+    const size_t nr = (size_t)(n_regions > 0 ? n_regions : 1);
+    return align_up(nr * 4) + align_up(((nr + CHUNK - 1) / CHUNK) * 4);
+}
+
+// shared by mf_region_frame (scratch = the caller's workspace) and
+// mf_region_frame_static (scratch = this GPU's copy of the static array)
+int region_frame_run(const double *rec, const float *inten, int64_t n_regions, int B, int conn3d,
+                     double crop_width, double crop_shape0, double crop_shape1,
+                     double minimum_area, double *out64, float *out32, int64_t *count,
+                     unsigned char *scratch, hipStream_t s)
+{
+    int64_t *d_count = nullptr;
+    int rc = device_view(count, &d_count, "count");
+    if (rc) return rc;
+    if (n_regions == 0) {
+        MF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
+        return MF_OK;
+    }
+    if (!rec || !inten || !out64 || !out32) return mf::fail(MF_EINVAL, "null pointer argument");
+    if (B < 1) return mf::fail(MF_EINVAL, "bad sizes");
+    double *d64 = nullptr;
+    float *d32 = nullptr;
+    if ((rc = device_view(out64, &d64, "out64")) || (rc = device_view(out32, &d32, "out32")))
+        return rc;
+    int32_t *sel = reinterpret_cast<int32_t *>(scratch);
+    int32_t *chunks = reinterpret_cast<int32_t *>(scratch + align_up((size_t)n_regions * 4));
+    const int n_chunks = (int)((n_regions + CHUNK - 1) / CHUNK);
+    // exclusive crop on the centroid with the reference's quirk: x is compared
+    // with shape[0] and y with shape[1] (decoding.py:244)
+    const KeepRow keep{rec, crop_width, crop_shape0 - crop_width, crop_shape1 - crop_width,
+                       minimum_area};
+    hipLaunchKernelGGL(keep_count, dim3((unsigned)n_chunks), dim3(NT), 0, s, keep, n_regions, chunks);
+    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, n_chunks,
+                       reinterpret_cast<unsigned long long *>(d_count));
+    hipLaunchKernelGGL(keep_emit, dim3((unsigned)n_chunks), dim3(NT), 0, s, keep, n_regions, chunks,
+                       sel);
+    // rows written over PCIe into mapped host memory: few workgroups, so the
+    // decode kernel of the next FOV keeps its CUs; into device memory: a full grid
+    unsigned g = (unsigned)((n_regions + GATHER_NT - 1) / GATHER_NT);
+    hipPointerAttribute_t at;
+    const bool to_device = hipPointerGetAttributes(&at, out64) == hipSuccess &&
+                           at.type == hipMemoryTypeDevice;
+    const unsigned g_max = to_device ? 512u : 4u;
+    if (g > g_max) g = g_max;
+    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel,
+                       reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
+                       conn3d, d64, d32);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t mf_region_frame_workspace_bytes(int64_t n_regions)
 {
     if (n_regions < 0 || n_regions > INT32_MAX) return mf::fail(MF_EINVAL, "bad region count");
-    const size_t nr = (size_t)(n_regions > 0 ? n_regions : 1);
-    size_t t = 0;
-    const hipError_t e =
-        rocprim::select(nullptr, t, rocprim::counting_iterator<int>(0), (int32_t *)nullptr,
-                        (unsigned long long *)nullptr, nr, KeepRow{nullptr, 0, 0, 0, 0});
-    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::select size query: %s", hipGetErrorString(e));
-    return (int64_t)(2 * align_up(nr * 4) + 256 + align_up(t));
+    return (int64_t)frame_scratch_bytes(n_regions);
 }
 
 extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_regions, int B,
@@ -792,56 +870,18 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
                                int64_t workspace_bytes, void *stream)
 {
     if (!count) return mf::fail(MF_EINVAL, "null pointer argument");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int64_t *d_count = nullptr;
-    int rc = device_view(count, &d_count, "count");
-    if (rc) return rc;
-    if (n_regions == 0) {
-        MF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
-        return MF_OK;
+    if (n_regions < 0 || n_regions > INT32_MAX) return mf::fail(MF_EINVAL, "bad region count");
+    if (n_regions > 0) {
+        if (!workspace) return mf::fail(MF_EINVAL, "null pointer argument");
+        const int64_t need = (int64_t)frame_scratch_bytes(n_regions);
+        if (workspace_bytes < need)
+            return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes",
+                            (long long)workspace_bytes, (long long)need);
     }
-    if (!rec || !inten || !out64 || !out32 || !workspace)
-        return mf::fail(MF_EINVAL, "null pointer argument");
-    if (n_regions < 0 || n_regions > INT32_MAX || B < 1)
-        return mf::fail(MF_EINVAL, "bad sizes");
-    const int64_t need = mf_region_frame_workspace_bytes(n_regions);
-    if (need < 0) return (int)need;
-    if (workspace_bytes < need)
-        return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes", (long long)workspace_bytes,
-                        (long long)need);
-    double *d64 = nullptr;
-    float *d32 = nullptr;
-    if ((rc = device_view(out64, &d64, "out64")) || (rc = device_view(out32, &d32, "out32")))
-        return rc;
-    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
-    const size_t col = align_up((size_t)n_regions * 4);
-    int32_t *sel = reinterpret_cast<int32_t *>(ws);
-    int32_t *gidx = reinterpret_cast<int32_t *>(ws + col);
-    void *temp = ws + 2 * col + 256;
-    size_t tb = (size_t)need - 2 * col - 256;
-    hipLaunchKernelGGL(group_index, dim3((unsigned)((n_regions + NT - 1) / NT)), dim3(NT), 0, s, rec,
-                       n_regions, conn3d, gidx);
-    // exclusive crop on the centroid with the reference's quirk: x is compared
-    // with shape[0] and y with shape[1] (decoding.py:244)
-    const KeepRow keep{rec, crop_width, crop_shape0 - crop_width, crop_shape1 - crop_width,
-                       minimum_area};
-    MF_HIP_CHECK(rocprim::select(temp, tb, rocprim::counting_iterator<int>(0), sel,
-                                 reinterpret_cast<unsigned long long *>(d_count),
-                                 (size_t)n_regions, keep, s));
-    // rows written over PCIe into mapped host memory: few workgroups, so the
-    // decode kernel of the next FOV keeps its CUs; into device memory: a full grid
-    unsigned g = (unsigned)((n_regions + GATHER_NT - 1) / GATHER_NT);
-    hipPointerAttribute_t at;
-    const bool to_device = hipPointerGetAttributes(&at, out64) == hipSuccess &&
-                           at.type == hipMemoryTypeDevice;
-    const unsigned g_max = to_device ? 512u : 4u;
-    if (g > g_max) g = g_max;
-    if (const char *e = std::getenv("MF_GATHER_WGS")) g = (unsigned)std::atoi(e);   // tuning aid
-    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel, gidx,
-                       reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
-                       conn3d ? 7 : 1, d64, d32);
-    MF_HIP_CHECK(hipGetLastError());
-    return MF_OK;
+    return region_frame_run(rec, inten, n_regions, B, conn3d, crop_width, crop_shape0, crop_shape1,
+                            minimum_area, out64, out32, count,
+                            reinterpret_cast<unsigned char *>(workspace),
+                            reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, int conn3d,
@@ -936,7 +976,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     // 1. assigned pixels in raster order, keyed by their component root
     hipLaunchKernelGGL(chunk_count<false>, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded,
                        (const uint32_t *)nullptr, vol, chunks);
-    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks);
+    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks,
+                       (unsigned long long *)nullptr);
     hipLaunchKernelGGL(emit_assigned, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol,
                        chunks, n_pixels, pix_a, keys_a);
     // 2. group them by root; the stable sort keeps raster order inside a
@@ -946,7 +987,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     // 3. region starts
     hipLaunchKernelGGL(chunk_count<true>, dim3(pl.pix_chunks), dim3(NT), 0, s,
                        (const int16_t *)nullptr, keys_b, n_pixels, chunks);
-    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.pix_chunks);
+    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.pix_chunks,
+                       (unsigned long long *)nullptr);
     hipLaunchKernelGGL(emit_boundaries, dim3(pl.pix_chunks), dim3(NT), 0, s, keys_b, n_pixels,
                        chunks, n_regions, offsets);
     // 4. emission order of the regions: (plane, barcode), label order inside
