@@ -40,6 +40,7 @@ extern "C" {
 #define MF_FRAME_COLS   10   /* float64 columns of mf_region_frame          */
 #define MF_PP_MAX_RADIUS 8   /* preprocess high-pass radius: sigma <= 4     */
 #define MF_HIST_BINS 65534   /* bins of np.arange(0, 65535), preprocess.py:114 */
+#define MF_FRAME_STATIC_MAX_ROWS 1048576 /* row limit of mf_region_frame_static */
 
 #define MF_CODEBOOK_UNIFORM 1 /* flag: all codewords share weight and value   */
 #define MF_CODEBOOK_MINHD_SHIFT   8  /* flags bits 8-15: minimum Hamming distance
@@ -186,6 +187,25 @@ int mf_region_frame(const double *rec, const float *inten, int64_t n_regions,
                     double crop_shape1, double minimum_area,
                     double *out64, float *out32, int64_t *count,
                     void *workspace, int64_t workspace_bytes, void *stream);
+
+/* mf_region_frame without a workspace argument, for callers that cannot
+ * allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, results
+ * and kernels as mf_region_frame; the scratch (kept-row indexes and chunk
+ * counts, 4.004 MiB) is a static __device__ array of the library, one copy per
+ * GPU held until the process ends, so the call itself allocates nothing.
+ *   - n_regions > MF_FRAME_STATIC_MAX_ROWS returns MF_EWORKSPACE;
+ *   - the device that holds `rec` must be the current device (MF_EINVAL else);
+ *   - every call on a GPU shares that GPU's array: calls that overlap on one
+ *     GPU (two streams, two threads) race -- serialise them, or use
+ *     mf_region_frame with one workspace per stream.  Nothing in the array has
+ *     to start at zero; each call overwrites what it reads. */
+int mf_region_frame_static(const double *rec, const float *inten,
+                           int64_t n_regions, int B, int conn3d,
+                           double crop_width, double crop_shape0,
+                           double crop_shape1, double minimum_area,
+                           double *out64, float *out32, int64_t *count,
+                           void *stream);
 
 /* ---- preprocess stage: what produces the uint16 stack
  * mf_decode_pixels reads.  Image batches are [n_images, H, W] row-major. ---- */

@@ -22,6 +22,7 @@ MF_FRAME_COLS = 10
 MF_DECODE_TRACES_DECODED_ONLY = 1
 MF_PP_MAX_RADIUS = 8
 MF_HIST_BINS = 65534
+MF_FRAME_STATIC_MAX_ROWS = 1048576
 
 # every symbol include/merfish_hip.h declares
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
@@ -29,6 +30,7 @@ EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
            'mf_decode_pixels', 'mf_label_components',
            'mf_region_workspace_bytes', 'mf_region_table',
            'mf_region_frame_workspace_bytes', 'mf_region_frame',
+           'mf_region_frame_static',
            'mf_high_pass_filter', 'mf_preprocess_workspace_bytes',
            'mf_deconvolve_lucyrichardson', 'mf_preprocess_images',
            'mf_deconvolve_lucyrichardson_guo')
@@ -81,6 +83,9 @@ def lib():
     L.mf_region_frame.restype = i32
     L.mf_region_frame.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64, f64,
                                   vp, vp, vp, vp, i64, vp]
+    L.mf_region_frame_static.restype = i32
+    L.mf_region_frame_static.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64,
+                                         f64, vp, vp, vp, vp]
     L.mf_high_pass_filter.restype = i32
     L.mf_high_pass_filter.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp]
     L.mf_preprocess_workspace_bytes.restype = i64

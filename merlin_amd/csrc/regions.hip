@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 
@@ -881,6 +882,74 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
     return region_frame_run(rec, inten, n_regions, B, conn3d, crop_width, crop_shape0, crop_shape1,
                             minimum_area, out64, out32, count,
                             reinterpret_cast<unsigned char *>(workspace),
+                            reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- allocation-free variant (no counterpart in the reference) -------------
+// Scratch of mf_region_frame_static: one copy per GPU, held until the process
+// ends.  `scratch` is a host-side stand-in for the array, never a device
+// address: host code only uses the per-device pointer hipGetSymbolAddress
+// returns.
+constexpr size_t FRAME_STATIC_BYTES =
+    (((size_t)MF_FRAME_STATIC_MAX_ROWS * 4 + 255) & ~size_t(255)) +
+    ((((size_t)MF_FRAME_STATIC_MAX_ROWS + CHUNK - 1) / CHUNK * 4 + 255) & ~size_t(255));
+static __device__ __align__(256) unsigned char scratch[FRAME_STATIC_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+unsigned char *g_scratch_ptr[MAX_DEVICES];     // this process's address of each GPU's copy
+std::mutex g_scratch_mutex;
+
+// Address of the current device's copy of `scratch`, resolved on the first
+// call on that device.
+int static_scratch(unsigned char **out, int *device)
+{
+    int dev = -1;
+    MF_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES)
+        return mf::fail(MF_EUNSUPPORTED, "device ordinal %d outside 0..%d", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        MF_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return mf::fail(MF_EHIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = reinterpret_cast<unsigned char *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    *device = dev;
+    return MF_OK;
+}
+}  // namespace
+
+extern "C" int mf_region_frame_static(const double *rec, const float *inten, int64_t n_regions,
+                                      int B, int conn3d, double crop_width, double crop_shape0,
+                                      double crop_shape1, double minimum_area, double *out64,
+                                      float *out32, int64_t *count, void *stream)
+{
+    if (!count) return mf::fail(MF_EINVAL, "null pointer argument");
+    if (n_regions < 0) return mf::fail(MF_EINVAL, "bad region count");
+    if (n_regions > MF_FRAME_STATIC_MAX_ROWS)
+        return mf::fail(MF_EWORKSPACE,
+                        "mf_region_frame_static holds at most %d rows, got %lld: use "
+                        "mf_region_frame with a workspace",
+                        MF_FRAME_STATIC_MAX_ROWS, (long long)n_regions);
+    unsigned char *ptr = nullptr;
+    int dev = -1;
+    int rc = static_scratch(&ptr, &dev);
+    if (rc) return rc;
+    if (rec) {
+        // the scratch used is the CURRENT device's: the table must live there
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, rec) != hipSuccess) {
+            (void)hipGetLastError();
+            return mf::fail(MF_EINVAL, "rec is not device memory");
+        }
+        if (at.type == hipMemoryTypeDevice && at.device != dev)
+            return mf::fail(MF_EINVAL, "rec lives on device %d but device %d is current", at.device,
+                            dev);
+    }
+    return region_frame_run(rec, inten, n_regions, B, conn3d, crop_width, crop_shape0, crop_shape1,
+                            minimum_area, out64, out32, count, ptr,
                             reinterpret_cast<hipStream_t>(stream));
 }
 
