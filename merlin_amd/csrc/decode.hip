@@ -42,7 +42,11 @@
 namespace {
 
 constexpr int TW = 64;              // tile width  = wave width
-constexpr int NTHREADS = 256;       // 4 waves
+#ifndef MF_NWAVES
+#define MF_NWAVES 4
+#endif
+constexpr int NWAVES = MF_NWAVES;   // waves per workgroup, stacked vertically
+constexpr int NTHREADS = 64 * NWAVES;
 #ifndef MF_GROUP
 #define MF_GROUP 4
 #endif
@@ -180,6 +184,19 @@ __device__ __forceinline__ f32x2 div_by_recip2(f32x2 n, f32x2 d, f32x2 r)
 #ifndef MF_D2_FMA
 #define MF_D2_FMA 1
 #endif
+#ifndef MF_TT_SEQ
+#define MF_TT_SEQ 0
+#endif
+// scheduling fences between the unrolled tasks / bits of the blur: keeps the
+// compiler from interleaving them (register pressure)
+#ifndef MF_SCHED_FENCE
+#define MF_SCHED_FENCE 0
+#endif
+#if MF_SCHED_FENCE
+#define MF_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MF_FENCE() ((void)0)
+#endif
 
 // exact float64 squared distance between the normalised trace and codeword
 // (mask, v): sum_b (x_b - c_b)^2 in bit order (sklearn's rdist loop)
@@ -218,7 +235,7 @@ decode_kernel(const DecodeArgs a)
 {
     using HT = typename HType<PIX>::type;
     constexpr bool IS_U16 = std::is_same<PIX, uint16_t>::value;
-    constexpr int TH = 4 * PPT;
+    constexpr int TH = NWAVES * PPT;
     constexpr int RH = TH + 2 * R;                 // rows staged per bit
     constexpr int RA = (R + 1) & ~1;               // radius rounded up to even
     constexpr int NW = 4 + 2 * RA;                 // window elements per task
@@ -373,6 +390,7 @@ decode_kernel(const DecodeArgs a)
                     // q = (bit_in_group * RH + row) * 16 + cg  ->  hs[4q .. 4q+3]
                     reinterpret_cast<u32x4 *>(hs)[q] = v;
                 }
+                MF_FENCE();
             }
         };
 
@@ -451,6 +469,7 @@ decode_kernel(const DecodeArgs a)
                             x[o + 1][b] = b >= B ? 0.0f : n.y;
                         }
                     }
+                    MF_FENCE();
                 }
                 __syncthreads();   // hs is rewritten by the next group
             } else {
@@ -576,6 +595,49 @@ decode_kernel(const DecodeArgs a)
                         af[ks] = *reinterpret_cast<const u32x4 *>(
                             lds_a + ((size_t)(ct + (lane & 31)) * MAXB +
                                      8 * ((2 * ks + half) ^ a_swz)) * 2);
+#if MF_TT_SEQ
+                    // one pixel tile at a time: 16 accumulator registers instead
+                    // of 32; with three or four waves per SIMD the other waves
+                    // cover the MFMA latency
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        f32x16 acc1;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc1[i] = 0.0f;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                            for (int s = 0; s < 3; ++s) {
+                                u32x4 bv;
+                                bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
+                                bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
+                                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    __builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, bv),
+                                    acc1, 0, 0, 0);
+                            }
+                        const float before = st[tt].best;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            float s4[4];
+                            if constexpr (UNI) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) s4[i] = acc1[4 * gq + i];
+                            } else {
+                                const int nl = ct + 8 * gq + 4 * half;
+                                const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
+                                const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
+                                s4[0] = fmaf(vv.x, acc1[4 * gq + 0], hh.x);
+                                s4[1] = fmaf(vv.y, acc1[4 * gq + 1], hh.y);
+                                s4[2] = fmaf(vv.z, acc1[4 * gq + 2], hh.z);
+                                s4[3] = fmaf(vv.w, acc1[4 * gq + 3], hh.w);
+                            }
+                            top2_update4<EXCL>(st[tt], score_key(s4[0], 4 * gq + 0),
+                                         score_key(s4[1], 4 * gq + 1), score_key(s4[2], 4 * gq + 2),
+                                         score_key(s4[3], 4 * gq + 3));
+                        }
+                        st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
+                    }
+#else
                     // both pixel tiles first, so the second chain of MFMAs
                     // runs under the first tile's epilogue
                     f32x16 acc[2];
@@ -627,6 +689,7 @@ decode_kernel(const DecodeArgs a)
                         }
                         st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
                     }
+#endif
                 }
             }
 
@@ -716,7 +779,7 @@ template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, bool EXCL
 int launch(DecodeArgs &a, hipStream_t stream)
 {
     using HT = typename HType<PIX>::type;
-    constexpr int TH = 4 * PPT, RH = TH + 2 * R;
+    constexpr int TH = NWAVES * PPT, RH = TH + 2 * R;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     const int64_t nt = (int64_t)a.tiles_x * a.tiles_y * a.Z;
