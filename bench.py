@@ -70,12 +70,83 @@ def cpu_baseline(codebook, img_plane, sf, bg, params):
                 params['minimum_area'])
         dt = time.perf_counter() - t0
     px = img_plane.shape[1] * img_plane.shape[2]
-    return {'value': px / dt / 1e6, 'unit': 'Mpx/s', 'cores': 1,
-            'kind': 'port',
-            'sample': 'one {}x{} plane x 16 bits of the same synthetic '
-                      'FOV: oracle decode_pixels + 140x extract_barcodes '
-                      '({:.1f} s)'.format(img_plane.shape[1],
-                                          img_plane.shape[2], dt)}
+    out = {'value': px / dt / 1e6, 'unit': 'Mpx/s', 'cores': 1,
+           'kind': 'port',
+           'sample': 'one {}x{} plane x 16 bits of the same synthetic '
+                     'FOV: oracle decode_pixels + 140x extract_barcodes '
+                     '({:.1f} s)'.format(img_plane.shape[1],
+                                         img_plane.shape[2], dt)}
+    # The reference as written (per-pixel Python loops + sklearn + skimage)
+    # cannot travel to the GPU box; it was timed in the build container by
+    # oracle/time_reference.py (1 core, 256^2..1024^2 planes, linear in pixels)
+    ref = os.path.join(ROOT, 'profiles', 'cpu_reference_baseline.json')
+    if os.path.exists(ref):
+        r = json.load(open(ref))
+        out['reference_as_written'] = {
+            'value': r['extrapolated']['Mpx_per_s'], 'unit': 'Mpx/s',
+            'fov_7z_s': r['extrapolated']['fov_7z_2048_s'],
+            'extrapolated': True, 'cores': r['cores'],
+            'host': r['cpu_model'] + ' (build container, not this host)',
+            'blur': r['blur'], 'source': 'profiles/cpu_reference_baseline.json'}
+    return out
+
+
+BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+
+
+def codebook_configs(dev):
+    """BASELINE configs 3 and 5: the large-codebook nearest-codeword
+    path, timed with HIP events around back-to-back decode launches.
+    flops: algorithmic = 2*N*B per pixel (the [px,B] x [B,N] contraction of
+    decoding.py:112-116); issued = 3 exact bf16 splits x 2 x Npad x K."""
+    from merlin_amd.codebook import random_weight_codebook
+    from merlin_amd.decode import Decode
+    from merlin_amd.synthetic import synthetic_fov
+    out = {}
+    for name, bits, words, z, seed, reps in (
+            ('config3_22bit_1000cw_1z', 22, 1000, 1, 7, 10),
+            ('config5_32bit_10000cw_10z', 32, 10000, 10, 11, 3)):
+        cb = random_weight_codebook(bits, words, 4, seed=seed)
+        task = Decode(cb, {'crop_width': 100}, device=dev)
+        img = synthetic_fov(cb.get_barcodes(), z, H, W, SPOTS_PER_PLANE,
+                            SEED, dev)
+        sf, bg = np.full(bits, 500.0), np.zeros(bits)
+        for _ in range(2):
+            v = task.decode_fov_device(img, sf, bg)
+        torch.cuda.synchronize(dev)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            v = task.decode_fov_device(img, sf, bg)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        k_ms = e0.elapsed_time(e1) / reps
+        del v
+        t0 = time.perf_counter()
+        for i in range(reps):
+            bc, vol = task.run_fov(img, sf, bg, fov=i)
+        torch.cuda.synchronize(dev)
+        fov_ms = (time.perf_counter() - t0) / reps * 1e3
+        px = z * H * W
+        npad = (words + 31) // 32 * 32
+        alg = 2.0 * words * bits * px
+        issued = 3 * 2.0 * npad * (16 if bits <= 16 else 32) * px
+        out[name] = {
+            'bits': bits, 'codewords': words, 'z': z,
+            'decode_kernel_ms': k_ms,
+            'decode_kernel_ms_per_plane': k_ms / z,
+            'decode_Mpx_per_s': px / k_ms / 1e3,
+            'run_fov_ms': fov_ms, 'records': len(bc),
+            'roofline': {'bound': 'mfma', 'unit': 'TFLOP/s',
+                         'peak': BF16_PEAK_TFLOPS,
+                         'achieved': alg / k_ms / 1e9,
+                         'frac': alg / k_ms / 1e9 / BF16_PEAK_TFLOPS,
+                         'issued_bf16': issued / k_ms / 1e9,
+                         'issued_frac': issued / k_ms / 1e9 / BF16_PEAK_TFLOPS}}
+        del img, bc, vol, task
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -86,6 +157,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-pipeline', action='store_true')
     ap.add_argument('--no-preprocess', action='store_true')
+    ap.add_argument('--no-codebooks', action='store_true')
+    ap.add_argument('--serial', action='store_true',
+                    help='one run_fov call per step instead of the pipelined run_fovs')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -131,7 +205,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if os.environ.get('BENCH_SERIAL'):       # one run_fov call per step
+    if args.serial:                          # one run_fov call per step
         def run(count):                      # noqa: F811
             bc = vol = None
             for i in range(count):
@@ -155,6 +229,33 @@ def main():
     n_records = len(bc)
     n_decoded = int((vol.decoded >= 0).sum())
     del bc, vol
+
+    # ---- the one collective of the path (outside the timed decode loop, which
+    # has none): OptimizeIteration's exchange of the per-fragment refactors,
+    # background refactors and barcode counts (optimize.py:328-345, 358-373,
+    # 406-408) as ONE packed [F, 2B+N] sum-all-reduce over RCCL ----
+    exchange = None
+    if dist_on:
+        from merlin_amd import optimize
+        F, N = 50, 140
+        mine = optimize.shard_fragments(F, rank, world)
+        rng = np.random.default_rng(rank)
+        rf, bgr = rng.uniform(0.5, 1.5, (len(mine), B)), rng.normal(size=(len(mine), B))
+        seen = rng.integers(0, 50, (len(mine), N)).astype(np.float64)
+        for _ in range(3):
+            got = optimize.exchange_fragment_results(rf, bgr, seen, mine, F, dev)
+        barrier()
+        t1 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            got = optimize.exchange_fragment_results(rf, bgr, seen, mine, F, dev)
+        torch.cuda.synchronize(dev)
+        ex_us = (time.perf_counter() - t1) / reps * 1e6
+        ok = bool(np.array_equal(got[0][mine], rf) and np.array_equal(got[2][mine], seen))
+        exchange = {'rccl_ranks': world, 'exchange_us': ex_us,
+                    'payload_bytes': F * (2 * B + N) * 8, 'own_rows_intact': ok,
+                    'note': 'one packed [F, 2B+N] float64 all-reduce per '
+                            'OptimizeIteration, host numpy in -> host numpy out'}
 
     # ---- roofline of the dominant kernel (decode_kernel): HIP events around
     # each of its launches inside the timed region, on the stream the library
@@ -181,13 +282,41 @@ def main():
     # traces for every decoded pixel (the FOV path keeps no others)
     alg_bytes = px_fov * (2 * B + 14) + n_decoded * 4 * B
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # SURVEY 8d's figure: 2B + 10 per pixel (float32 distances, no traces)
+    survey_bytes = px_fov * (2 * B + 10)
 
-    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc
-    # passes, see profiles/README.md); bench.py cannot read PMCs itself
-    traffic = None
+    # HBM bytes and VALU instructions per launch come from PMC counters, which
+    # need separate rocprofv3 --pmc passes (dev/profile.sh, dev/
+    # profile_counters.sh) and cannot be read from inside this process.  The
+    # files record the sha256 of the kernel source they were measured on: a
+    # kernel edited since then reports null instead of a stale number.
+    import hashlib
+    src_hash = hashlib.sha256(open(os.path.join(
+        ROOT, 'merlin_amd', 'csrc', 'decode.hip'), 'rb').read()).hexdigest()
+    traffic = valu = None
+    stale = []
     tfile = os.path.join(ROOT, 'profiles', 'decode_traffic.json')
     if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+        t = json.load(open(tfile))
+        if t.get('decode_hip_sha256') == src_hash:
+            traffic = t.get('hbm_bytes_per_launch')
+        else:
+            stale.append('profiles/decode_traffic.json')
+    cfile = os.path.join(ROOT, 'profiles', 'decode_counters.json')
+    if os.path.exists(cfile):
+        c = json.load(open(cfile))
+        if c.get('decode_hip_sha256') == src_hash:
+            n_valu = c['per_launch']['SQ_INSTS_VALU']
+            # issue-bound floor: 1024 SIMDs, one wave64 VALU instruction per 2
+            # cycles each (157 TFLOP/s fp32 vector peak), at the 2.4 GHz peak
+            floor_ms = n_valu * 2 / (256 * 4) / 2.4e9 * 1e3
+            valu = {'wave_instructions_per_launch': n_valu,
+                    'per_64px_row': n_valu / (px_fov / 64),
+                    'issue_floor_ms': floor_ms,
+                    'frac_of_issue_peak': floor_ms / k_ms,
+                    'source': 'profiles/decode_counters.json'}
+        else:
+            stale.append('profiles/decode_counters.json')
 
     # ---- PCIe-inclusive rate (never `value`): the same FOVs starting in
     # page-locked HOST memory, uploaded by the pinned multi-buffered pipeline
@@ -266,6 +395,9 @@ def main():
                 'bound': 'hbm', 'kernel': 'decode_kernel<u16,R=2,B<=16>',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                'frac_survey_bytes': survey_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'survey_bytes': survey_bytes, 'valu': valu,
+                'stale_counter_files': stale,
                 'kernel_ms': k_ms, 'launches_timed': len(k_events),
                 'alone': {'kernel_ms': k_alone_ms,
                           'achieved': alg_bytes / (k_alone_ms * 1e-3) / 1e9,
@@ -279,6 +411,10 @@ def main():
             out['host_pipeline'] = host_line
         if pre_line is not None:
             out['preprocess'] = pre_line
+        if exchange is not None:
+            out['optimize_exchange'] = exchange
+        if world == 1 and not args.no_codebooks:
+            out['codebooks'] = codebook_configs(dev)
         if not args.no_cpu_baseline and world == 1:
             plane = fovs[0][:, 0].cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(codebook, plane, sf, bg,

@@ -38,6 +38,7 @@ extern "C" {
 #define MF_MAX_RADIUS    4   /* blur radius: ksize <= 9, i.e. sigma <= 2    */
 #define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
 #define MF_FRAME_COLS   10   /* float64 columns of mf_region_frame          */
+#define MF_TYPED_F32_COLS 7  /* float32 columns of mf_region_frame_typed    */
 #define MF_PP_MAX_RADIUS 8   /* preprocess high-pass radius: sigma <= 4     */
 #define MF_HIST_BINS 65534   /* bins of np.arange(0, 65535), preprocess.py:114 */
 #define MF_FRAME_STATIC_MAX_ROWS 1048576 /* row limit of mf_region_frame_static */
@@ -48,6 +49,7 @@ extern "C" {
 #define MF_CODEBOOK_WEIGHT_SHIFT 16  /* flags bits 16-23: its codeword weight    */
 
 #define MF_DECODE_TRACES_DECODED_ONLY 1 /* mf_decode_pixels flag, see there   */
+#define MF_DECODE_KEEP_RUNNER_UP     2 /* mf_decode_pixels flag, see there   */
 
 #define MF_DTYPE_U16     0
 #define MF_DTYPE_F32     1
@@ -98,6 +100,11 @@ int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
  *   flags      MF_DECODE_TRACES_DECODED_ONLY: write the traces only of pixels
  *              whose decoded value is >= 0 (all that the region table reads);
  *              the other entries of `traces` are left untouched.
+ *              MF_DECODE_KEEP_RUNNER_UP: always track the second-best codeword
+ *              and take the exact-tie path, also for codebooks whose minimum
+ *              Hamming distance makes a runner-up within the threshold
+ *              impossible (MHD4 at thresholds <= 0.5176); same results, used
+ *              to check that shortcut.
  *
  * Blur: ksize = 2*ceil(2*sigma)+1 <= 9, BORDER_REFLECT_101, exact integer
  * arithmetic for u16.  Nearest codeword replaces sklearn NearestNeighbors
@@ -188,6 +195,27 @@ int mf_region_frame(const double *rec, const float *inten, int64_t n_regions,
                     double *out64, float *out32, int64_t *count,
                     void *workspace, int64_t workspace_bytes, void *stream);
 
+/* mf_region_frame with the rows already in the barcode database's column
+ * types (merlin/util/barcodedb.py:46-65; the astype of write_barcodes,
+ * :264-266), so the record sink takes them without a host-side cast:
+ *   out_u16   u16 [2][n_regions]  barcode_id, area (area wraps modulo 2^16 as
+ *             numpy's astype does)
+ *   out_f32   f32 [MF_TYPED_F32_COLS][n_regions]  mean_intensity, max_intensity,
+ *             mean_distance, min_distance, x, y, z (float64 rounded to nearest)
+ *   out_index i32 [n_regions]     position of the row inside its (plane, barcode)
+ *             frame
+ *   out_inten f32 [B][n_regions]  per-bit intensities
+ *   out_xy64  f64 [2][n_regions]  x, y unrounded, for a global aligner
+ *             (analysis/globalalign.py:141-148); may be NULL
+ * Same filter, row order, workspace and count as mf_region_frame. */
+int mf_region_frame_typed(const double *rec, const float *inten,
+                          int64_t n_regions, int B, int conn3d,
+                          double crop_width, double crop_shape0,
+                          double crop_shape1, double minimum_area,
+                          uint16_t *out_u16, float *out_f32, int32_t *out_index,
+                          float *out_inten, double *out_xy64, int64_t *count,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+
 /* mf_region_frame without a workspace argument, for callers that cannot
  * allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, results
@@ -221,7 +249,10 @@ int mf_high_pass_filter(const uint16_t *image, int n_images, int H, int W,
                         void *stream);
 
 /* Scratch for the two calls below; `batch` images are deconvolved together
- * (34 B/px each: keep batch * H * W * 34 under the 256 MiB Infinity Cache). */
+ * (34 B/px each).  Larger batches are faster up to about 4 GiB of workspace
+ * (30 frames of 2048 x 2048: enough strips to fill the chip evenly; the working
+ * set streams through HBM either way, it does not fit the 256 MiB Infinity
+ * Cache beyond one frame). */
 int64_t mf_preprocess_workspace_bytes(int batch, int H, int W);
 
 /* deconvolve_lucyrichardson (merlin/util/deconvolve.py:70-133), odd

@@ -19,7 +19,9 @@ MF_MAX_BITS = 32
 MF_MAX_RADIUS = 4
 MF_REC_COLS = 12
 MF_FRAME_COLS = 10
+MF_TYPED_F32_COLS = 7
 MF_DECODE_TRACES_DECODED_ONLY = 1
+MF_DECODE_KEEP_RUNNER_UP = 2
 MF_PP_MAX_RADIUS = 8
 MF_HIST_BINS = 65534
 MF_FRAME_STATIC_MAX_ROWS = 1048576
@@ -30,7 +32,7 @@ EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
            'mf_decode_pixels', 'mf_label_components',
            'mf_region_workspace_bytes', 'mf_region_table',
            'mf_region_frame_workspace_bytes', 'mf_region_frame',
-           'mf_region_frame_static',
+           'mf_region_frame_static', 'mf_region_frame_typed',
            'mf_high_pass_filter', 'mf_preprocess_workspace_bytes',
            'mf_deconvolve_lucyrichardson', 'mf_preprocess_images',
            'mf_deconvolve_lucyrichardson_guo')
@@ -86,6 +88,10 @@ def lib():
     L.mf_region_frame_static.restype = i32
     L.mf_region_frame_static.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64,
                                          f64, vp, vp, vp, vp]
+    L.mf_region_frame_typed.restype = i32
+    L.mf_region_frame_typed.argtypes = [vp, vp, i64, i32, i32, f64, f64, f64,
+                                        f64, vp, vp, vp, vp, vp, vp, vp, i64,
+                                        vp]
     L.mf_high_pass_filter.restype = i32
     L.mf_high_pass_filter.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp]
     L.mf_preprocess_workspace_bytes.restype = i64

@@ -807,7 +807,6 @@ int launch(DecodeArgs &a, hipStream_t stream)
     // CUs much better than an exactly-resident persistent grid (measured:
     // 2.86 ms at 2 WGs/CU vs 2.19 ms at 32 WGs/CU for one 7-z FOV)
     int64_t grid = (int64_t)cus * 32;
-    if (const char *gm = std::getenv("MF_GRID_MULT")) grid = (int64_t)cus * std::atoi(gm);   // tuning aid
     if (grid > nt) grid = nt;
     grid = (grid + 7) & ~int64_t(7);
 
@@ -1064,7 +1063,8 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     if (dist_dtype != MF_DTYPE_F32 && dist_dtype != MF_DTYPE_F64)
         return mf::fail(MF_EINVAL, "distance dtype %d not f32/f64", dist_dtype);
     if (!(sigma >= 0)) return mf::fail(MF_EINVAL, "sigma must be >= 0");
-    if (flags & ~MF_DECODE_TRACES_DECODED_ONLY) return mf::fail(MF_EINVAL, "unknown flags %d", flags);
+    if (flags & ~(MF_DECODE_TRACES_DECODED_ONLY | MF_DECODE_KEEP_RUNNER_UP))
+        return mf::fail(MF_EINVAL, "unknown flags %d", flags);
     if (traces && tr_pix_stride < 1) return mf::fail(MF_EINVAL, "traces pixel stride must be >= 1");
     const int ksize = (int)(2 * std::ceil(2 * sigma) + 1);   // decoding.py:94
     const int R = ksize / 2;
@@ -1083,7 +1083,7 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     a.z_stride = img_z_stride;
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.N = N; a.Npad = h.Npad;
     a.uniform = (codebook_flags & MF_CODEBOOK_UNIFORM) != 0;
-    a.exclusive = a.uniform && std::getenv("MF_NO_EXCLUSIVE") == nullptr &&
+    a.exclusive = a.uniform && !(flags & MF_DECODE_KEEP_RUNNER_UP) &&
                   codebook_exclusive((codebook_flags >> MF_CODEBOOK_WEIGHT_SHIFT) & 0xff,
                                      (codebook_flags >> MF_CODEBOOK_MINHD_SHIFT) & 0xff,
                                      distance_threshold);

@@ -804,13 +804,18 @@ int dispatch_fused(int R, const LrArgs &a, int n, hipStream_t s)
     return mf::fail(MF_EUNSUPPORTED, "deconvolution filter radius %d > 6", R);
 }
 
-// MF_LR_SPLIT=1 (environment, read once): the two-launch iteration
-// (lr_stream_kernel reblur + update through a ratio buffer) instead of the
-// fused one; kept for comparison and as a fall-back.
+// The two-launch iteration (lr_stream_kernel reblur + update through a ratio
+// buffer) instead of the fused one is kept for comparison: development builds
+// (-DMF_LR_TUNE) read MF_LR_SPLIT=1 from the environment once; the release
+// build has no environment knobs.
 bool use_fused()
 {
+#ifdef MF_LR_TUNE
     static const bool fused = !(std::getenv("MF_LR_SPLIT") && std::atoi(std::getenv("MF_LR_SPLIT")));
     return fused;
+#else
+    return true;
+#endif
 }
 
 template <typename WT>

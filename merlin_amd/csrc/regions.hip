@@ -788,6 +788,45 @@ frame_gather(const double *__restrict__ rec, const float *__restrict__ inten,
     }
 }
 
+// The same rows in the barcode database's column types
+// (merlin/util/barcodedb.py:46-65, the astype of write_barcodes :264-266):
+// uint16 barcode_id / area, float32 statistics and coordinates, int32 index.
+// float64 -> float32 rounds to nearest like numpy's astype; area wraps modulo
+// 2^16 like the C cast numpy makes.
+struct TypedOut {
+    uint16_t *u16;      // [2][n]  barcode_id, area
+    float *f32;         // [7][n]  mean_intensity, max_intensity, mean_distance,
+                        //         min_distance, x, y, z
+    int32_t *index;     // [n]     position inside the (plane, barcode) frame
+    double *xy64;       // [2][n]  x, y in float64 (for the global aligner) or null
+};
+
+__global__ void __launch_bounds__(GATHER_NT)
+frame_gather_typed(const double *__restrict__ rec, const float *__restrict__ inten,
+                   const int32_t *__restrict__ sel,
+                   const unsigned long long *__restrict__ count, int64_t n_reg, int B,
+                   int conn3d, TypedOut o, float *__restrict__ out32)
+{
+    const int64_t m = (int64_t)*count;
+    const int zcol = conn3d ? 7 : 1;
+    const int cols[7] = {3, 4, 5, 6, 9, 8, zcol};
+    for (int64_t i = (int64_t)blockIdx.x * GATHER_NT + threadIdx.x; i < m;
+         i += (int64_t)gridDim.x * GATHER_NT) {
+        const int64_t r = sel[i];
+        const double *row = rec + r * MF_REC_COLS;
+        o.u16[i] = (uint16_t)(int64_t)row[0];
+        o.u16[n_reg + i] = (uint16_t)(int64_t)row[2];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) o.f32[(int64_t)c * n_reg + i] = (float)row[cols[c]];
+        o.index[i] = (int32_t)group_index(rec, r, conn3d);
+        if (o.xy64) {
+            o.xy64[i] = row[9];
+            o.xy64[n_reg + i] = row[8];
+        }
+        for (int b = 0; b < B; ++b) out32[(int64_t)b * n_reg + i] = inten[r * B + b];
+    }
+}
+
 // device-side address of a buffer the kernels may write: device memory or
 // page-locked host memory that is mapped into the device's address space
 template <typename T>
@@ -814,7 +853,7 @@ inline size_t frame_scratch_bytes(int64_t n_regions)
 int region_frame_run(const double *rec, const float *inten, int64_t n_regions, int B, int conn3d,
                      double crop_width, double crop_shape0, double crop_shape1,
                      double minimum_area, double *out64, float *out32, int64_t *count,
-                     unsigned char *scratch, hipStream_t s)
+                     unsigned char *scratch, hipStream_t s, const TypedOut *typed = nullptr)
 {
     int64_t *d_count = nullptr;
     int rc = device_view(count, &d_count, "count");
@@ -823,12 +862,24 @@ int region_frame_run(const double *rec, const float *inten, int64_t n_regions, i
         MF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int64_t), s));
         return MF_OK;
     }
-    if (!rec || !inten || !out64 || !out32) return mf::fail(MF_EINVAL, "null pointer argument");
+    if (!rec || !inten || (!out64 && !typed) || !out32)
+        return mf::fail(MF_EINVAL, "null pointer argument");
     if (B < 1) return mf::fail(MF_EINVAL, "bad sizes");
     double *d64 = nullptr;
     float *d32 = nullptr;
-    if ((rc = device_view(out64, &d64, "out64")) || (rc = device_view(out32, &d32, "out32")))
+    TypedOut t{nullptr, nullptr, nullptr, nullptr};
+    if ((rc = device_view(out32, &d32, "out32"))) return rc;
+    if (typed) {
+        if (!typed->u16 || !typed->f32 || !typed->index)
+            return mf::fail(MF_EINVAL, "null pointer argument");
+        if ((rc = device_view(typed->u16, &t.u16, "out_u16")) ||
+            (rc = device_view(typed->f32, &t.f32, "out_f32")) ||
+            (rc = device_view(typed->index, &t.index, "out_index")))
+            return rc;
+        if (typed->xy64 && (rc = device_view(typed->xy64, &t.xy64, "out_xy64"))) return rc;
+    } else if ((rc = device_view(out64, &d64, "out64"))) {
         return rc;
+    }
     int32_t *sel = reinterpret_cast<int32_t *>(scratch);
     int32_t *chunks = reinterpret_cast<int32_t *>(scratch + align_up((size_t)n_regions * 4));
     const int n_chunks = (int)((n_regions + CHUNK - 1) / CHUNK);
@@ -845,13 +896,18 @@ int region_frame_run(const double *rec, const float *inten, int64_t n_regions, i
     // decode kernel of the next FOV keeps its CUs; into device memory: a full grid
     unsigned g = (unsigned)((n_regions + GATHER_NT - 1) / GATHER_NT);
     hipPointerAttribute_t at;
-    const bool to_device = hipPointerGetAttributes(&at, out64) == hipSuccess &&
+    const bool to_device = hipPointerGetAttributes(&at, out32) == hipSuccess &&
                            at.type == hipMemoryTypeDevice;
     const unsigned g_max = to_device ? 512u : 4u;
     if (g > g_max) g = g_max;
-    hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel,
-                       reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
-                       conn3d, d64, d32);
+    if (typed)
+        hipLaunchKernelGGL(frame_gather_typed, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel,
+                           reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
+                           conn3d, t, d32);
+    else
+        hipLaunchKernelGGL(frame_gather, dim3(g), dim3(GATHER_NT), 0, s, rec, inten, sel,
+                           reinterpret_cast<const unsigned long long *>(d_count), n_regions, B,
+                           conn3d, d64, d32);
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
 }
@@ -883,6 +939,29 @@ extern "C" int mf_region_frame(const double *rec, const float *inten, int64_t n_
                             minimum_area, out64, out32, count,
                             reinterpret_cast<unsigned char *>(workspace),
                             reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int mf_region_frame_typed(const double *rec, const float *inten, int64_t n_regions,
+                                     int B, int conn3d, double crop_width, double crop_shape0,
+                                     double crop_shape1, double minimum_area, uint16_t *out_u16,
+                                     float *out_f32, int32_t *out_index, float *out_inten,
+                                     double *out_xy64, int64_t *count, void *workspace,
+                                     int64_t workspace_bytes, void *stream)
+{
+    if (!count) return mf::fail(MF_EINVAL, "null pointer argument");
+    if (n_regions < 0 || n_regions > INT32_MAX) return mf::fail(MF_EINVAL, "bad region count");
+    if (n_regions > 0) {
+        if (!workspace) return mf::fail(MF_EINVAL, "null pointer argument");
+        const int64_t need = (int64_t)frame_scratch_bytes(n_regions);
+        if (workspace_bytes < need)
+            return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes",
+                            (long long)workspace_bytes, (long long)need);
+    }
+    const TypedOut typed{out_u16, out_f32, out_index, out_xy64};
+    return region_frame_run(rec, inten, n_regions, B, conn3d, crop_width, crop_shape0, crop_shape1,
+                            minimum_area, nullptr, out_inten, count,
+                            reinterpret_cast<unsigned char *>(workspace),
+                            reinterpret_cast<hipStream_t>(stream), &typed);
 }
 
 // ---- allocation-free variant (no counterpart in the reference) -------------

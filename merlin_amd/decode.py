@@ -15,9 +15,32 @@ import torch
 from merlin_amd.decoding import PixelBasedDecoder, DecodedVolume
 
 
-class Decode(object):
+def shard_fovs(fovs, rank: int, world: int):
+    """FOV number i of the list belongs to rank i mod world."""
+    if not (0 <= rank < world):
+        raise ValueError('rank {} outside 0..{}'.format(rank, world - 1))
+    return [f for i, f in enumerate(fovs) if i % world == rank]
 
-    def __init__(self, codebook, parameters=None, device=None):
+
+class Decode(object):
+    """Parameters as analysis/decode.py:46-66.  What the reference's task gets
+    from its data set is passed in instead:
+
+    * ``database`` (run_fov / run_fovs): a ``merlin_amd.barcodedb.BarcodeDB``;
+      the FOV's records then take the typed device path into it
+      (``get_barcode_database().write_barcodes``, decode.py:225-230) and
+      ``remove_z_duplicated_barcodes`` works on the database's table exactly
+      as decode.py:170-175 does (read back, filter, empty, rewrite);
+    * ``outputDirectory``: where ``write_decoded_images`` puts
+      ``decoded_<fov>.tif`` (decode.py:165-168, 196-213; nothing is written
+      without a directory);
+    * ``memory_map`` (decode.py:131-139) asks the reference to keep the
+      ``decode_3d`` pixel traces in a memory-mapped file instead of RAM.  Here
+      those traces never reach host memory (they stay in HBM), so the
+      parameter is accepted and changes nothing, results included."""
+
+    def __init__(self, codebook, parameters=None, device=None,
+                 outputDirectory=None, overlap=True):
         self.parameters = dict(parameters or {})
         p = self.parameters
         p.setdefault('crop_width', 100)
@@ -34,6 +57,9 @@ class Decode(object):
         self.cropWidth = p['crop_width']
         self._codebook = codebook
         self.decoder = PixelBasedDecoder(codebook, device=device)
+        self.outputDirectory = outputDirectory
+        # overlap=False: every stage of run_fovs on one stream (measurement)
+        self.overlap = bool(overlap)
 
     def get_codebook(self):
         return self._codebook
@@ -41,8 +67,7 @@ class Decode(object):
     def _side_stream(self, dev):
         """Stream for mf_region_frame's PCIe-bound gather, created once.
         (A CU-masked stream was measured too: slower than an ordinary one.)"""
-        import os
-        if os.environ.get('MF_NO_SIDE'):           # tuning aid: no overlap
+        if not self.overlap:
             return None
         if getattr(self, '_side', None) is None:
             with torch.cuda.device(dev):
@@ -51,14 +76,12 @@ class Decode(object):
 
     def _table_stream(self, dev):
         """Second compute stream for the region-table stage of the pipelined
-        FOV loop (MF_NO_TABLE_STREAM=1: tuning aid, everything on one stream)."""
-        import os
-        if os.environ.get('MF_NO_TABLE_STREAM'):
+        FOV loop."""
+        if not self.overlap:
             return None
         if getattr(self, '_tbl', None) is None:
             with torch.cuda.device(dev):
-                self._tbl = torch.cuda.Stream(
-                    dev, priority=int(os.environ.get('MF_TABLE_PRIORITY', '0')))
+                self._tbl = torch.cuda.Stream(dev)
         return self._tbl
 
     def decode_fov_device(self, imageStack: torch.Tensor, scaleFactors,
@@ -76,14 +99,37 @@ class Decode(object):
             lowPassSigma=p['lowpass_sigma'], returnTraces=returnTraces,
             distanceDtype=torch.float32 if p['decode_3d'] else torch.float64)
 
-    def _finish_fov(self, pending, vol, fov, globalAligner, zPositions):
+    def _finish_fov(self, pending, vol, fov, globalAligner, zPositions,
+                    database=None):
         p = self.parameters
+        zpos = zPositions if zPositions is not None \
+            else list(range(vol.shape[0]))
+        if p['write_decoded_images'] and self.outputDirectory is not None:
+            from merlin_amd import imagewriter
+            os.makedirs(self.outputDirectory, exist_ok=True)
+            imagewriter.save_decoded_images(
+                os.path.join(self.outputDirectory,
+                             'decoded_{}.tif'.format(fov)), vol)
+        if database is not None:
+            # decode.py:225-230 then :170-175, on the database's typed table
+            database.write_barcodes(
+                self.decoder._frame_finish_typed(pending, vol.bit_count, fov,
+                                                 globalAligner), fov=fov)
+            if p['remove_z_duplicated_barcodes']:
+                from merlin_amd import barcodefilters
+                bc = barcodefilters.remove_zplane_duplicates_all_barcodeids(
+                    database.get_barcodes(fov=fov),
+                    p['z_duplicate_zPlane_threshold'],
+                    p['z_duplicate_xy_pixel_threshold'], zpos)
+                database.empty_database(fov)
+                database.write_barcodes(bc, fov=fov)
+            return database.get_barcodes(fov=fov)
         bc = self.decoder._frame_finish(pending, vol.bit_count, fov,
                                         globalAligner)
         if p['remove_z_duplicated_barcodes']:
+            # (the reference filters the database's float32 columns; without a
+            # database the float64 frame is filtered as it is)
             from merlin_amd import barcodefilters
-            zpos = zPositions if zPositions is not None \
-                else list(range(vol.shape[0]))
             bc = barcodefilters.remove_zplane_duplicates_all_barcodeids(
                 bc, p['z_duplicate_zPlane_threshold'],
                 p['z_duplicate_xy_pixel_threshold'], zpos)
@@ -114,7 +160,7 @@ class Decode(object):
             vol.decoded.record_stream(lbl)
         return vol, lab
 
-    def _enqueue_table(self, vol, lab, side=None):
+    def _enqueue_table(self, vol, lab, side=None, typed=False, wantXY64=False):
         """Stage 2: region table + frame rows.  Blocks once, on the pixel /
         region counts that size the tables."""
         p = self.parameters
@@ -127,7 +173,8 @@ class Decode(object):
             table = self.decoder.region_table(vol, is3D, pendingLabels=lab)
             return self.decoder._frame_enqueue(
                 table, is3D, vol.bit_count, self.cropWidth,
-                p['minimum_area'], shape, stream=side)
+                p['minimum_area'], shape, stream=side, typed=typed,
+                wantXY64=wantXY64)
         # the sort / region statistics of this FOV on their own stream, beside
         # the decode kernel of the next FOV (already queued on the main one)
         tbl.wait_event(lab[3])
@@ -135,7 +182,8 @@ class Decode(object):
             table = self.decoder.region_table(vol, is3D, pendingLabels=lab)
             pending = self.decoder._frame_enqueue(
                 table, is3D, vol.bit_count, self.cropWidth,
-                p['minimum_area'], shape, stream=side)
+                p['minimum_area'], shape, stream=side, typed=typed,
+                wantXY64=wantXY64)
         for t in (vol.decoded, vol.magnitudes, vol.distances, vol.traces,
                   lab[0]):
             if t is not None:
@@ -143,7 +191,7 @@ class Decode(object):
         return pending
 
     def run_fov(self, imageStack: torch.Tensor, scaleFactors, backgrounds,
-                fov: int, globalAligner=None, zPositions=None):
+                fov: int, globalAligner=None, zPositions=None, database=None):
         """decode.py:92-175 for one FOV.  Returns (barcodes DataFrame,
         DecodedVolume); the volume's decoded/magnitudes/distances tensors are
         the images _save_decoded_images would write.
@@ -152,12 +200,13 @@ class Decode(object):
         order the reference writes them (plane, barcode index, label order);
         decode_3d labels the volume with 26-connectivity."""
         vol, lab = self._enqueue_decode(imageStack, scaleFactors, backgrounds)
-        pending = self._enqueue_table(vol, lab)
+        pending = self._enqueue_table(vol, lab, typed=database is not None,
+                                      wantXY64=globalAligner is not None)
         return self._finish_fov(pending, vol, fov, globalAligner,
-                                zPositions), vol
+                                zPositions, database), vol
 
     def run_fovs(self, imageStacks, scaleFactors, backgrounds, fovs=None,
-                 globalAligner=None, zPositions=None):
+                 globalAligner=None, zPositions=None, database=None):
         """run_fov over a sequence of FOVs (the loop the reference spreads
         over fragment processes, decode.py:68-75), yielding (barcodes,
         DecodedVolume) per FOV in order.
@@ -168,12 +217,13 @@ class Decode(object):
         the sort / region statistics of FOV k run on two more compute streams
         beside that decode kernel, its frame rows cross PCIe on a copy stream
         and FOV k-1's DataFrame is assembled on the host meanwhile
-        (MF_NO_LABEL_STREAM / MF_NO_TABLE_STREAM / MF_NO_SIDE: tuning aids)."""
+        (``overlap=False`` at construction: everything on one stream)."""
         dev = self.decoder._dev()
         side = self._side_stream(dev)
         lbl = None
-        if side is not None and self._table_stream(dev) is not None \
-                and not os.environ.get('MF_NO_LABEL_STREAM'):
+        typed = database is not None
+        xy64 = globalAligner is not None
+        if side is not None and self._table_stream(dev) is not None:
             if getattr(self, '_lbl', None) is None:
                 with torch.cuda.device(dev):
                     self._lbl = torch.cuda.Stream(dev)
@@ -183,25 +233,53 @@ class Decode(object):
 
         def finish(t):
             return self._finish_fov(t[1], t[0], t[2], globalAligner,
-                                    zPositions), t[0]
+                                    zPositions, database), t[0]
 
         for k, stack in enumerate(imageStacks):
             fov = k if fovs is None else fovs[k]
             nxt = self._enqueue_decode(stack, scaleFactors, backgrounds,
                                        lbl) + (fov,)
             if decoded is not None:
-                pending = self._enqueue_table(decoded[0], decoded[1], side)
+                pending = self._enqueue_table(decoded[0], decoded[1], side,
+                                              typed, xy64)
                 if tabled is not None:
                     yield finish(tabled)
                 tabled = (decoded[0], pending, decoded[2])
             decoded = nxt
         if decoded is not None:
-            pending = self._enqueue_table(decoded[0], decoded[1], side)
+            pending = self._enqueue_table(decoded[0], decoded[1], side,
+                                              typed, xy64)
             if tabled is not None:
                 yield finish(tabled)
             tabled = (decoded[0], pending, decoded[2])
         if tabled is not None:
             yield finish(tabled)
+
+    def run_fovs_sharded(self, stackProvider, scaleFactors, backgrounds, fovs,
+                         rank=None, world=None, group=None,
+                         globalAligner=None, zPositions=None, database=None):
+        """This rank's share of the fragment loop (core/analysistask.py:
+        285-297 runs ``_run_analysis(i)`` for every fragment, one process
+        each; analysis/decode.py:71-72: a fragment is a FOV).  FOV number i of
+        ``fovs`` belongs to rank ``i mod world``; FOVs are independent, so
+        there is no collective.  ``stackProvider(fov)`` returns the uint16
+        [B,Z,H,W] device tensor of a FOV and is only called for this rank's
+        FOVs.  rank / world default to the torch.distributed group's.
+        Yields (fov, barcodes, DecodedVolume) in this rank's FOV order."""
+        if rank is None or world is None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank(group)
+                world = dist.get_world_size(group)
+            else:
+                rank, world = 0, 1
+        mine = shard_fovs(fovs, rank, world)
+        stacks = (stackProvider(f) for f in mine)
+        results = self.run_fovs(stacks, scaleFactors, backgrounds, fovs=mine,
+                                globalAligner=globalAligner,
+                                zPositions=zPositions, database=database)
+        for f, (bc, vol) in zip(mine, results):
+            yield f, bc, vol
 
     def run_fovs_from_host(self, hostStacks, scaleFactors, backgrounds,
                            fovs=None, globalAligner=None, zPositions=None,

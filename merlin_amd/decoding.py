@@ -28,6 +28,10 @@ COLUMN_NAMES = ['barcode_id', 'fov', 'mean_intensity', 'max_intensity',
                 'global_x', 'global_y', 'global_z', 'cell_index']
 
 
+_NUMPY_DTYPES = {torch.int16: np.int16, torch.float32: np.float32,
+                 torch.float64: np.float64}
+
+
 def normalize(x):
     """decoding.py:17-22"""
     norm = np.linalg.norm(x)
@@ -64,11 +68,11 @@ def _sum_rows_by_code(ids: np.ndarray, rows: np.ndarray, count: int
                        minlength=count * bits).reshape(count, bits)
 
 
-# Frame rows are staged in HBM and moved to the host by the copy engine;
-# MF_FRAME_DIRECT=1 (A/B switch) has the gather kernel write them over PCIe
+# Frame rows are staged in HBM and moved to the host by the copy engine.
+# False has the gather kernel write them over PCIe into mapped pinned memory
 # instead, which costs the next FOV's decode kernel 5 % (measured; more with more
 # workgroups storing into mapped host memory).
-_FRAME_VIA_COPY = not os.environ.get('MF_FRAME_DIRECT')
+_FRAME_VIA_COPY = True
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -208,7 +212,8 @@ class PixelBasedDecoder(object):
                              magnitudeThreshold: float = 1,
                              lowPassSigma: float = 1,
                              returnTraces=True,
-                             distanceDtype=torch.float64) -> DecodedVolume:
+                             distanceDtype=torch.float64,
+                             keepRunnerUp=False) -> DecodedVolume:
         """decode_pixels on a device-resident stack.
 
         imageData: uint16 / float32 tensor [B,H,W] or [B,Z,H,W] on the GPU
@@ -260,6 +265,8 @@ class PixelBasedDecoder(object):
                 traces = None
             ddt = _lib.MF_DTYPE_F64 if distanceDtype == torch.float64 \
                 else _lib.MF_DTYPE_F32
+            if keepRunnerUp:        # MF_DECODE_KEEP_RUNNER_UP, see the header
+                flags |= _lib.MF_DECODE_KEEP_RUNNER_UP
             cb = self._codebook_device()
             import ctypes
             fp = ctypes.POINTER(ctypes.c_float)
@@ -278,7 +285,8 @@ class PixelBasedDecoder(object):
         # keep the input alive until the stream has consumed it
         imageData.record_stream(torch.cuda.current_stream(dev))
         vol = DecodedVolume(decoded, mags, dist, traces, B)
-        vol.traces_decoded_only = bool(flags)
+        vol.traces_decoded_only = bool(
+            flags & _lib.MF_DECODE_TRACES_DECODED_ONLY)
         return vol
 
     def decode_pixels(self, imageData: np.ndarray,
@@ -306,29 +314,78 @@ class PixelBasedDecoder(object):
         vol = self.decode_pixels_device(
             img.to(self._dev()), scaleFactors, backgrounds, distanceThreshold,
             magnitudeThreshold, lowPassSigma, True, torch.float64)
-        decoded = vol.decoded[0].cpu().numpy()
-        mags = vol.magnitudes[0].cpu().numpy()
-        traces = vol.traces[0].cpu().numpy()
-        dist = vol.distances[0].cpu().numpy()
-        self._remember((decoded, mags, traces, dist), vol)
+        def to_host(t):
+            # into an array that numpy owns, so that a caller may make it
+            # writeable again
+            a = np.empty(tuple(t.shape), dtype=_NUMPY_DTYPES[t.dtype])
+            torch.from_numpy(a).copy_(t)
+            return a
+        decoded = to_host(vol.decoded[0])
+        mags = to_host(vol.magnitudes[0])
+        traces = to_host(vol.traces[0])
+        dist = to_host(vol.distances[0])
+        # The arrays are handed out read-only: while they stay so, the
+        # device-resident volume is known to hold the same contents and the
+        # extraction calls reuse it.  A caller that wants to edit them sets
+        # ``flags.writeable = True``; the extraction calls then upload the
+        # arrays' current contents (see _lookup).
+        for a in (decoded, mags, traces, dist):
+            a.flags.writeable = False
+        self._remember((decoded, mags, traces, dist), vol, None)
         return decoded, mags, traces, dist
 
     # ------------------------------------------------ device result caching --
 
-    def _remember(self, arrays, vol):
+    _CACHED_VOLUMES = 2       # device volumes kept for the extraction calls
+
+    @staticmethod
+    def _content_key(decodedImage, pixelMagnitudes):
+        """Checksum of the two images an in-place edit would touch
+        (``di[pm < t] = -1`` and the like)."""
+        try:
+            import xxhash
+            h = xxhash.xxh3_64()
+            for a in (decodedImage, pixelMagnitudes):
+                h.update(np.ascontiguousarray(a).data)
+            return h.intdigest()
+        except ImportError:
+            import zlib
+            k = 0
+            for a in (decodedImage, pixelMagnitudes):
+                k = zlib.adler32(np.ascontiguousarray(a).data, k)
+            return k
+
+    def _remember(self, arrays, vol, key):
         refs = tuple(weakref.ref(a) for a in arrays)
-        self._recent.append((refs, vol))
-        del self._recent[:-4]
+        self._recent.append((refs, vol, key))
+        del self._recent[:-self._CACHED_VOLUMES]
 
     def _lookup(self, decodedImage, pixelMagnitudes, pixelTraces, distances):
-        """DecodedVolume for arrays this decoder returned earlier (matched by
-        identity), else upload the given arrays."""
-        for refs, vol in reversed(self._recent):
+        """DecodedVolume for the given images.
+
+        A cached device volume is reused only when it is known to hold the
+        arrays' CURRENT contents: the arrays are the very objects an earlier
+        call saw (identity) and either they are still the read-only arrays
+        decode_pixels returned, or a checksum of decodedImage and
+        pixelMagnitudes taken at upload time still matches.  Anything else --
+        other arrays, arrays made writeable, edited contents -- is uploaded
+        again, so the result always follows the arrays as the reference's
+        does.  Entries whose arrays are gone are dropped."""
+        self._recent = [e for e in self._recent
+                        if all(r() is not None for r in e[0])]
+        for refs, vol, key in reversed(self._recent):
             d, m, t, ds = (r() for r in refs)
-            if d is decodedImage and m is pixelMagnitudes \
-                    and t is pixelTraces \
-                    and (distances is None or ds is distances):
+            if not (d is decodedImage and m is pixelMagnitudes
+                    and t is pixelTraces
+                    and (distances is None or ds is distances)):
+                continue
+            if key is None:
+                if not any(a.flags.writeable for a in (d, m, t, ds)):
+                    return vol
+            elif key == self._content_key(decodedImage, pixelMagnitudes):
                 return vol
+            self._recent = [e for e in self._recent if e[1] is not vol]
+            break
         dev = self._dev()
         dec = np.ascontiguousarray(decodedImage, dtype=np.int16)
         is3d = np.asarray(pixelTraces).ndim == 4
@@ -337,7 +394,11 @@ class PixelBasedDecoder(object):
         def up(a, dt=None):
             a = np.ascontiguousarray(a) if dt is None \
                 else np.ascontiguousarray(a, dtype=dt)
-            return torch.from_numpy(a).to(dev)
+            import warnings
+            with warnings.catch_warnings():
+                # read-only arrays are only read here
+                warnings.simplefilter('ignore', category=UserWarning)
+                return torch.from_numpy(a).to(dev)
         mags = up(pixelMagnitudes, np.float32)
         tr = up(pixelTraces, np.float32)
         if distances is None:
@@ -349,12 +410,12 @@ class PixelBasedDecoder(object):
         if not is3d:
             mags, tr = mags[None], tr[None]
             dist = None if dist is None else dist[None]
-        vol = DecodedVolume(torch.from_numpy(dec).to(dev), mags, dist, tr,
-                            tr.shape[1])
+        vol = DecodedVolume(up(dec), mags, dist, tr, tr.shape[1])
         keep = (decodedImage, pixelMagnitudes, pixelTraces,
                 distances if distances is not None else pixelMagnitudes)
         if all(isinstance(a, np.ndarray) for a in keep):
-            self._remember(keep, vol)
+            self._remember(keep, vol,
+                           self._content_key(decodedImage, pixelMagnitudes))
         return vol
 
     # --------------------------------------------------------- region table --
@@ -513,23 +574,34 @@ class PixelBasedDecoder(object):
         return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
 
     def _frame_enqueue(self, table: RegionTable, is3D, bitCount, cropWidth,
-                       minimumArea, cropShape, stream=None):
+                       minimumArea, cropShape, stream=None, typed=False,
+                       wantXY64=False):
         """Launch mf_region_frame for every row of a device-resident table:
         the crop / area filter and the column gather run on the GPU, which
         writes only the kept rows, column-major; three asynchronous copies
         bring them into page-locked buffers.
         Returns the pending state for _frame_finish.  With ``stream`` the work
         runs on that side stream (after what the current stream has queued),
-        so it overlaps whatever the caller launches next."""
+        so it overlaps whatever the caller launches next.  With ``typed`` the
+        rows come in the barcode database's column types
+        (mf_region_frame_typed) for _frame_finish_typed; ``wantXY64`` adds the
+        unrounded x, y a global aligner needs."""
         rec = table.rec_d
         n = rec.shape[0]
         if n == 0:
             return None
         dev = rec.device
         L = _lib.lib()
-        h64 = self._pinned((_lib.MF_FRAME_COLS, n), torch.float64)
         h32 = self._pinned((bitCount, n), torch.float32)
         hcount = self._pinned((1,), torch.int64)
+        if typed:
+            hosts = [self._pinned((2, n), torch.uint16),
+                     self._pinned((_lib.MF_TYPED_F32_COLS, n), torch.float32),
+                     self._pinned((n,), torch.int32),
+                     self._pinned((2, n), torch.float64) if wantXY64
+                     else None]
+        else:
+            hosts = [self._pinned((_lib.MF_FRAME_COLS, n), torch.float64)]
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             run = cur if stream is None else stream
@@ -541,27 +613,89 @@ class PixelBasedDecoder(object):
                 if _FRAME_VIA_COPY:
                     # rows into device buffers, then the copy engine moves
                     # them: no workgroup sits on PCIe beside the next decode
-                    o64 = torch.empty_like(h64, device=dev)
+                    outs = [None if h is None else torch.empty_like(h, device=dev)
+                            for h in hosts]
                     o32 = torch.empty_like(h32, device=dev)
                     ocount = torch.empty_like(hcount, device=dev)
                 else:
-                    o64, o32, ocount = h64, h32, hcount
-                _lib.check(L.mf_region_frame(
-                    rec.data_ptr(), table.inten_d.data_ptr(), n, bitCount,
-                    int(is3D), float(cropWidth), float(cropShape[0]),
-                    float(cropShape[1]), float(minimumArea), o64.data_ptr(),
-                    o32.data_ptr(), ocount.data_ptr(), ws.data_ptr(),
-                    ws_bytes, run.cuda_stream))
+                    outs, o32, ocount = hosts, h32, hcount
+                common = (rec.data_ptr(), table.inten_d.data_ptr(), n,
+                          bitCount, int(is3D), float(cropWidth),
+                          float(cropShape[0]), float(cropShape[1]),
+                          float(minimumArea))
+                if typed:
+                    _lib.check(L.mf_region_frame_typed(
+                        *common, outs[0].data_ptr(), outs[1].data_ptr(),
+                        outs[2].data_ptr(), o32.data_ptr(), _ptr(outs[3]),
+                        ocount.data_ptr(), ws.data_ptr(), ws_bytes,
+                        run.cuda_stream))
+                else:
+                    _lib.check(L.mf_region_frame(
+                        *common, outs[0].data_ptr(), o32.data_ptr(),
+                        ocount.data_ptr(), ws.data_ptr(), ws_bytes,
+                        run.cuda_stream))
                 if _FRAME_VIA_COPY:
                     hcount.copy_(ocount, non_blocking=True)
-                    h64.copy_(o64, non_blocking=True)
-                    h32.copy_(o32, non_blocking=True)
-                    for t in (o64, o32, ocount):
-                        t.record_stream(run)
+                    for h, o in zip(hosts + [h32], outs + [o32]):
+                        if h is not None:
+                            h.copy_(o, non_blocking=True)
+                            o.record_stream(run)
+                    ocount.record_stream(run)
                 done = torch.cuda.Event()
                 done.record(run)
         # `table` and `ws` stay referenced until the event has fired
-        return (table, ws, h64, h32, hcount, done)
+        if typed:
+            return (table, ws, hosts, h32, hcount, done)
+        return (table, ws, hosts[0], h32, hcount, done)
+
+    def _frame_finish_typed(self, pending, bitCount, fov, globalAligner):
+        """Wait for a typed _frame_enqueue and wrap its columns as
+        ``barcodedb.TypedBarcodes``: what ``BarcodeDB.write_barcodes`` would
+        make of the reference's DataFrame (its astype to the column types,
+        barcodedb.py:264-266), without the float64 frame in between.  fov and
+        cell_index are constants; the global columns are the local ones unless
+        a global aligner maps the unrounded centroids."""
+        from merlin_amd.barcodedb import TypedBarcodes
+        names = ['intensity_{}'.format(i) for i in range(bitCount)]
+        if pending is None:
+            m = 0
+            u16 = np.zeros((2, 0), np.uint16)
+            f32 = np.zeros((_lib.MF_TYPED_F32_COLS, 0), np.float32)
+            idx = np.zeros(0, np.int32)
+            a32 = np.zeros((bitCount, 0), np.float32)
+            xy = None
+        else:
+            _, _, hosts, h32, hcount, done = pending
+            done.synchronize()
+            m = int(hcount[0])
+            u16 = hosts[0].numpy()[:, :m]
+            f32 = hosts[1].numpy()[:, :m]
+            idx = hosts[2].numpy()[:m]
+            xy = None if hosts[3] is None else hosts[3].numpy()[:, :m]
+            a32 = h32.numpy()[:, :m]
+        gx, gy, gz = f32[4], f32[5], f32[6]
+        if globalAligner is not None and m:
+            if xy is None:
+                raise ValueError('a global aligner needs wantXY64')
+            centroids = np.stack([f32[6].astype(np.float64), xy[0], xy[1]],
+                                 axis=1)
+            g = np.asarray(globalAligner.fov_coordinate_array_to_global(
+                fov, centroids))
+            gx, gy, gz = (g[:, 1].astype(np.float32),
+                          g[:, 2].astype(np.float32),
+                          g[:, 0].astype(np.float32))
+        cols = {
+            'barcode_id': u16[0],
+            'fov': np.full(m, fov).astype(np.uint16),
+            'mean_intensity': f32[0], 'max_intensity': f32[1],
+            'area': u16[1], 'mean_distance': f32[2], 'min_distance': f32[3],
+            'x': f32[4], 'y': f32[5], 'z': f32[6],
+            'global_x': gx, 'global_y': gy, 'global_z': gz,
+            'cell_index': np.full(m, -1, dtype=np.int32),
+        }
+        for i, c in enumerate(names):
+            cols[c] = a32[i]
+        return TypedBarcodes(cols, idx.astype(np.int64))
 
     def _frame_finish(self, pending, bitCount, fov, globalAligner,
                       zOverride=None) -> pandas.DataFrame:
@@ -642,12 +776,17 @@ class PixelBasedDecoder(object):
         table = self.region_table(vol, is3D)
         Z, H, W = vol.shape
         cropShape = (Z, H, W) if is3D else (H, W)
-        if is3D or (zPlane is None and zIndex is None):
+        if is3D or (zPlane is None and zIndex is None and Z > 1):
             # every row; in 2-D mode the z column is each row's own plane
+            # (a multi-plane 2-D volume has no counterpart in the reference)
             return self._frame_on_device(
                 table, is3D, vol.bit_count, fov, cropWidth, globalAligner,
                 minimumArea, cropShape)
         if Z == 1 and zPlane in (None, 0) and len(table):
+            if zIndex is None:
+                # the reference assigns None into the float centroid column:
+                # NaN (decoding.py:209-211)
+                zIndex = float('nan')
             # one plane decoded on its own (OptimizeIteration's fragments):
             # every row, z = the caller's zIndex
             return self._frame_on_device(

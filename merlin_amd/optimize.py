@@ -34,8 +34,10 @@ def shard_fragments(count: int, rank: int, world: int) -> List[int]:
 def all_gather_rows(local: np.ndarray, rows: Sequence[int], total: int,
                     device=None, group=None) -> np.ndarray:
     """Every rank contributes ``local[k]`` as row ``rows[k]`` of a [total, C]
-    float64 matrix; returns the full matrix on every rank.  Implemented as a
-    sum-all-reduce over a zero-initialised buffer (exact: x + 0 == x)."""
+    float64 matrix; returns the full matrix on every rank.  ONE sum-all-reduce
+    over a zero-initialised buffer (exact: x + 0 == x, NaN rows stay NaN).  On
+    the nccl (RCCL) backend the buffer is built and reduced on the GPU and
+    crosses PCIe once each way; gloo reduces the host buffer."""
     local = np.asarray(local, dtype=np.float64)
     cols = local.shape[1:] if local.ndim > 1 else ()
     full = np.zeros((total,) + tuple(cols), dtype=np.float64)
@@ -44,13 +46,41 @@ def all_gather_rows(local: np.ndarray, rows: Sequence[int], total: int,
     dist = _dist()
     if dist is None or dist.get_world_size(group) == 1:
         return full
-    backend = dist.get_backend(group)
     t = torch.from_numpy(full)
-    if backend == 'nccl':
-        t = t.to(device if device is not None
-                 else torch.device('cuda', torch.cuda.current_device()))
+    if dist.get_backend(group) == 'nccl':
+        t = t.pin_memory().to(
+            device if device is not None
+            else torch.device('cuda', torch.cuda.current_device()),
+            non_blocking=True)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
+
+
+def exchange_fragment_results(refactors: np.ndarray, bgRefactors: np.ndarray,
+                              counts: np.ndarray, rows: Sequence[int],
+                              total: int, device=None, group=None):
+    """The one exchange step of an iteration (optimize.py:328-345, 358-373,
+    406-408 read every fragment's files): this rank's scale refactors [n,B],
+    background refactors [n,B] and barcode counts [n,N] packed side by side
+    into one [total, 2B+N] matrix -> a single all-reduce -> the three full
+    matrices on every rank."""
+    B, N = refactors.shape[1], counts.shape[1]
+    packed = np.concatenate([refactors, bgRefactors, counts], axis=1) \
+        if len(rows) else np.zeros((0, 2 * B + N))
+    full = all_gather_rows(packed, rows, total, device, group)
+    return full[:, :B], full[:, B:2 * B], full[:, 2 * B:]
+
+
+def broadcast_from_rank0(obj, group=None):
+    """``obj`` of rank 0 on every rank (tiny Python objects: the fragment
+    draw)."""
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0)
+                               if group is not None else 0, group=group)
+    return box[0]
 
 
 def pixel_histogram(stack: torch.Tensor) -> torch.Tensor:
@@ -116,11 +146,13 @@ class OptimizeIteration(object):
         if 'fov_index' in p:
             p['fov_per_iteration'] = len(p['fov_index'])
         else:
-            # optimize.py:43-50; every rank must draw the same fragments
+            # optimize.py:43-50.  Every rank must work on the same draw: rank 0
+            # draws (from OS entropy when seed is None, like the reference) and
+            # the list is broadcast.
             rng = np.random.RandomState(seed)
-            p['fov_index'] = [
+            p['fov_index'] = broadcast_from_rank0([
                 [int(rng.choice(list(fovs))), int(rng.choice(list(range(zCount))))]
-                for _ in range(p['fov_per_iteration'])]
+                for _ in range(p['fov_per_iteration'])], group)
         self._codebook = codebook
         self._previous = previousIteration
         self._initial = None if initialScaleFactors is None \
@@ -208,10 +240,9 @@ class OptimizeIteration(object):
 
         # one exchange per iteration (every rank used the same previous
         # factors, so previous_scale_factors[F,B] is a broadcast row)
-        self._refactors = all_gather_rows(rf, mine, F, self._device, self._group)
-        self._bg_refactors = all_gather_rows(bgr, mine, F, self._device,
-                                             self._group)
-        self._counts = all_gather_rows(seen, mine, F, self._device, self._group)
+        self._refactors, self._bg_refactors, self._counts = \
+            exchange_fragment_results(rf, bgr, seen, mine, F, self._device,
+                                      self._group)
         self._previous_factors = np.tile(scaleFactors, (F, 1))
         self._previous_backgrounds = np.tile(backgrounds, (F, 1))
         self._complete = True

@@ -56,6 +56,10 @@ def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# One workspace per (device, stream), reused by every call on that stream (up
+# to ~4 GiB each at the default batch).  release_workspaces() returns them to
+# torch's allocator; a long-lived process that preprocesses on many side
+# streams should call it when a stream retires.
 _workspaces = {}
 
 
@@ -67,6 +71,17 @@ def _workspace(device, batch, H, W):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def release_workspaces(device=None) -> int:
+    """Drop the cached deconvolution workspaces (of one device, or all);
+    returns the number of bytes released.  Work already queued keeps its
+    buffer alive through torch's stream-ordered allocator."""
+    index = None if device is None else torch.device(device).index
+    freed = 0
+    for key in [k for k in _workspaces if index is None or k[0] == index]:
+        freed += _workspaces.pop(key).numel()
+    return freed
 
 
 def _as_images(t: torch.Tensor):

@@ -289,7 +289,7 @@ def test_argument_errors(gpu_device):
         PixelBasedDecoder(ArrayCodebook(np.ones((3, 40), dtype=int)))
 
 
-def test_exclusive_codebook_path_matches_runner_up_path(gpu_device, monkeypatch):
+def test_exclusive_codebook_path_matches_runner_up_path(gpu_device):
     """MHD4 codebook + threshold <= 0.5176: the kernel drops the runner-up
     (no two codewords can both be within reach, decode.hip codebook_exclusive).
     Same decoded image and magnitudes as the top-2 path; distances identical
@@ -307,11 +307,9 @@ def test_exclusive_codebook_path_matches_runner_up_path(gpu_device, monkeypatch)
     sf = rng.uniform(300, 600, 16)
     bg = np.zeros(16)
     for thr in (0.5176, 0.5167, 0.3):
-        monkeypatch.delenv('MF_NO_EXCLUSIVE', raising=False)
         a = dec.decode_pixels_device(img, sf, bg, thr, 1, 1)
-        monkeypatch.setenv('MF_NO_EXCLUSIVE', '1')
-        b = dec.decode_pixels_device(img, sf, bg, thr, 1, 1)
-        monkeypatch.delenv('MF_NO_EXCLUSIVE', raising=False)
+        b = dec.decode_pixels_device(img, sf, bg, thr, 1, 1,
+                                     keepRunnerUp=True)
         da, db = a.decoded.cpu().numpy(), b.decoded.cpu().numpy()
         assert np.array_equal(da, db) and (da >= 0).sum() > 1000
         assert torch.equal(a.magnitudes, b.magnitudes)

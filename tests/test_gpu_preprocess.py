@@ -293,3 +293,15 @@ def test_guo_variant(gpu_device):
         pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 15, 2, 2)
     with pytest.raises(NotImplementedError):
         pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 8, 2, 2)
+
+
+def test_release_workspaces(gpu_device):
+    """The per-stream deconvolution workspaces are cached for reuse and can be
+    handed back."""
+    from merlin_amd import preprocess
+    img = np.random.default_rng(0).integers(0, 4000, (2, 64, 64)).astype(np.uint16)
+    a = preprocess.deconvolve_lucyrichardson(img[0], 9, 2, 3)
+    assert preprocess.release_workspaces(gpu_device) > 0
+    assert preprocess.release_workspaces() == 0
+    b = preprocess.deconvolve_lucyrichardson(img[0], 9, 2, 3)
+    assert np.array_equal(a, b)

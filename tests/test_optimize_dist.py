@@ -128,6 +128,37 @@ def _free_port():
     return p
 
 
+class _StubDecode(object):
+    """Decode with the GPU stage replaced: run_fovs yields a table that is a
+    function of the stack alone, so what is under test is the sharding
+    (Decode.run_fovs_sharded, core/analysistask.py:285-297)."""
+
+    def __new__(cls):
+        from merlin_amd.decode import Decode
+        task = object.__new__(Decode)
+        task.run_fovs = cls.run_fovs
+        return task
+
+    @staticmethod
+    def run_fovs(stacks, scaleFactors, backgrounds, fovs=None, **kw):
+        import pandas
+        for k, stack in enumerate(stacks):
+            yield pandas.DataFrame({
+                'fov': np.full(3, fovs[k]),
+                'x': stack[:3].astype(np.float64) * scaleFactors[0]}), None
+
+
+def _fov_stack(fov):
+    return np.arange(5) + 10 * fov
+
+
+def _sharded_tables(rank, world):
+    task = _StubDecode()
+    fovs = [3, 4, 7, 9, 12]
+    return {f: bc for f, bc, _ in task.run_fovs_sharded(
+        _fov_stack, np.full(16, 2.0), np.zeros(16), fovs, rank, world)}
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -138,9 +169,23 @@ def _worker(rank, world, port, q):
         hist = torch.zeros((16, 65534), dtype=torch.float64)
         hist[:, 10 + rank] = rank + 1.0
         total = optimize.summed_pixel_histogram(hist)
+        # the default fragment draw (seed None: OS entropy) is rank 0's on
+        # every rank
+        cb = ArrayCodebook(load_golden('g3_edges')['codebook'])
+        draw = optimize.OptimizeIteration(
+            cb, {'fov_per_iteration': 6}, fovs=range(50), zCount=7,
+            fragmentFunction=_fake_fragment).parameters['fov_index']
+        draws = [None, None]
+        dist.all_gather_object(draws, draw)
+        # Decode's fragment loop sharded over the group (rank / world taken
+        # from it)
+        task = _StubDecode()
+        mine = {f: bc for f, bc, _ in task.run_fovs_sharded(
+            _fov_stack, np.full(16, 2.0), np.zeros(16), [3, 4, 7, 9, 12])}
         q.put((rank, it1.get_scale_factors(), it1.get_backgrounds(),
                it2.get_scale_factors(), it2.get_backgrounds(),
-               it2.get_barcode_count_history(), total[:, 8:14]))
+               it2.get_barcode_count_history(), total[:, 8:14], draws,
+               {f: bc.to_dict('list') for f, bc in mine.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -165,6 +210,37 @@ def test_gloo_world2_matches_single_process():
         assert np.array_equal(r[4], exp[1][1], equal_nan=True)
         assert np.array_equal(r[5][1], exp[1][2])
         assert r[6][0].tolist() == [0, 0, 1, 2, 0, 0]
+        assert r[7][0] == r[7][1] and len(r[7][0]) == 6
+    # Decode sharding: FOV number i on rank i mod 2, union == the single-rank run
+    single = _sharded_tables(0, 1)
+    assert sorted(res[0][8]) == [3, 7, 12] and sorted(res[1][8]) == [4, 9]
+    union = dict(res[0][8])
+    union.update(res[1][8])
+    assert sorted(union) == sorted(single)
+    for f, bc in single.items():
+        assert union[f] == bc.to_dict('list')
+
+
+def test_exchange_is_one_packed_all_reduce():
+    rng = np.random.default_rng(3)
+    rf, bgr, seen = rng.normal(size=(3, 16)), rng.normal(size=(3, 16)), \
+        rng.integers(0, 9, (3, 140)).astype(float)
+    rf[1, 2] = np.nan
+    a, b, c = optimize.exchange_fragment_results(rf, bgr, seen, [0, 2, 5], 7)
+    assert a.shape == (7, 16) and b.shape == (7, 16) and c.shape == (7, 140)
+    assert np.array_equal(a[[0, 2, 5]], rf, equal_nan=True)
+    assert np.array_equal(b[[0, 2, 5]], bgr) and np.array_equal(c[[0, 2, 5]], seen)
+    assert not a[[1, 3, 4, 6]].any() and not c[[1, 3, 4, 6]].any()
+    e = optimize.exchange_fragment_results(rf[:0], bgr[:0], seen[:0], [], 4)
+    assert e[0].shape == (4, 16) and e[2].shape == (4, 140)
+
+
+def test_shard_fovs():
+    from merlin_amd.decode import shard_fovs
+    assert shard_fovs([5, 6, 7, 8, 9], 1, 2) == [6, 8]
+    assert shard_fovs([], 0, 3) == []
+    with pytest.raises(ValueError):
+        shard_fovs([1], 2, 2)
 
 
 def test_row_norms_have_the_bits_of_per_row_linalg_norm():
