@@ -158,6 +158,9 @@ def main():
     ap.add_argument('--no-host-pipeline', action='store_true')
     ap.add_argument('--no-preprocess', action='store_true')
     ap.add_argument('--no-codebooks', action='store_true')
+    ap.add_argument('--backend', default='nccl',
+                    help='torch.distributed backend for --gpus > 1 (nccl = RCCL; '
+                         'gloo only to rehearse the multi-rank path on one GPU)')
     ap.add_argument('--serial', action='store_true',
                     help='one run_fov call per step instead of the pipelined run_fovs')
     args = ap.parse_args()
@@ -171,7 +174,10 @@ def main():
     dev = torch.device('cuda', local_rank)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from merlin_amd.decode import Decode
     from merlin_amd.synthetic import synthetic_fov
@@ -222,7 +228,8 @@ def main():
     dt = time.perf_counter() - t0
     k_events, task.kernel_events = task.kernel_events, None
     if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -252,7 +259,8 @@ def main():
         torch.cuda.synchronize(dev)
         ex_us = (time.perf_counter() - t1) / reps * 1e6
         ok = bool(np.array_equal(got[0][mine], rf) and np.array_equal(got[2][mine], seen))
-        exchange = {'rccl_ranks': world, 'exchange_us': ex_us,
+        exchange = {'rccl_ranks': world, 'backend': args.backend,
+                    'exchange_us': ex_us,
                     'payload_bytes': F * (2 * B + N) * 8, 'own_rows_intact': ok,
                     'note': 'one packed [F, 2B+N] float64 all-reduce per '
                             'OptimizeIteration, host numpy in -> host numpy out'}

@@ -184,9 +184,36 @@ __device__ __forceinline__ f32x2 div_by_recip2(f32x2 n, f32x2 d, f32x2 r)
 #ifndef MF_D2_FMA
 #define MF_D2_FMA 1
 #endif
-#ifndef MF_TT_SEQ
-#define MF_TT_SEQ 0
+// Per bit-count class (<= 16 bits / <= 32 bits): pixel rows per thread, waves
+// per SIMD the register budget is set for, and whether the two 32-pixel
+// accumulator tiles of a row are worked one after the other (16 registers
+// instead of 32).  Measured per 7-z FOV (16 bits, 140 codewords): 4 rows x 2
+// waves 1.40 ms, 4 rows x 3 waves sequential 1.22, 2 rows x 4 waves
+// sequential 1.20.
+#ifndef MF_PPT16
+#define MF_PPT16 2
 #endif
+#ifndef MF_WPS16
+#define MF_WPS16 4
+#endif
+#ifndef MF_SEQ16
+#define MF_SEQ16 1
+#endif
+#ifndef MF_PPT32
+#define MF_PPT32 2
+#endif
+#ifndef MF_WPS32
+#define MF_WPS32 2
+#endif
+#ifndef MF_SEQ32
+#define MF_SEQ32 0
+#endif
+// (mixed-weight codebooks carry the per-codeword tables: one wave fewer)
+constexpr int waves_per_simd(int maxb, bool uni)
+{
+    return maxb <= 16 ? (uni ? MF_WPS16 : (MF_WPS16 > 3 ? 3 : MF_WPS16)) : MF_WPS32;
+}
+constexpr bool tiles_in_sequence(int maxb) { return maxb <= 16 ? MF_SEQ16 : MF_SEQ32; }
 // scheduling fences between the unrolled tasks / bits of the blur: keeps the
 // compiler from interleaving them (register pressure)
 #ifndef MF_SCHED_FENCE
@@ -220,17 +247,11 @@ __device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask
     return d2;
 }
 
-#ifndef MF_WAVES_PER_SIMD
-#define MF_WAVES_PER_SIMD 2
-#endif
-#ifndef MF_PPT16
-#define MF_PPT16 4
-#endif
 
 // FULL: B == MAXB and the reciprocal division applies, both known at compile
 // time (the common 16-bit / 32-bit codebooks): no per-bit guards.
 template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, bool EXCL>
-__global__ void __launch_bounds__(NTHREADS, MF_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(NTHREADS, waves_per_simd(MAXB, UNI))
 decode_kernel(const DecodeArgs a)
 {
     using HT = typename HType<PIX>::type;
@@ -296,6 +317,19 @@ decode_kernel(const DecodeArgs a)
     const int t_hi = min(a.n_tiles, t_lo + per_xcd);
     const int t_step = gridDim.x >> 3;
 
+    // byte offset of task k's window inside a group's block of bit planes
+    // (fast_ok guarantees it fits 32 bits)
+    constexpr int NTASK_ = (GROUP * (NWAVES * PPT + 2 * R) * 16 + NTHREADS - 1) / NTHREADS;
+    uint32_t voff[NTASK_];
+#pragma unroll
+    for (int k = 0; k < NTASK_; ++k) {
+        const int q = tid + k * NTHREADS;
+        const int rem = q % ((NWAVES * PPT + 2 * R) * 16);
+        voff[k] = (uint32_t)(((int64_t)(q / ((NWAVES * PPT + 2 * R) * 16)) * a.bit_stride +
+                              (int64_t)(rem >> 4) * W + 4 * (rem & 15)) *
+                             (int64_t)sizeof(PIX));
+    }
+
     for (int t = t_lo + (blockIdx.x >> 3); t < t_hi; t += t_step) {
         const int tx = t % a.tiles_x;
         const int ty = (t / a.tiles_x) % a.tiles_y;
@@ -311,22 +345,40 @@ decode_kernel(const DecodeArgs a)
         for (int j = 0; j <= 2 * R; ++j) kd[j] = (double)a.kfix[j];
 
         // ---- global -> register windows for one group of bits ----
+        // Interior tiles: the task's window sits at a tile-invariant byte
+        // offset voff[k] (one register per task, worked out before the tile
+        // loop) from a base that is uniform over the workgroup.
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));      // keeps the index arithmetic of the
+                                             // border path out of the registers
+                                             // the tile loop carries
         auto prefetch = [&](int g) {
+            const char *gbase = reinterpret_cast<const char *>(img) +
+                                ((int64_t)(g * GROUP) * a.bit_stride + (int64_t)z * a.z_stride +
+                                 (int64_t)(y0 - R) * W + (x0 - RA)) * (int64_t)sizeof(PIX);
 #pragma unroll
             for (int k = 0; k < NTASK; ++k) {
-                const int q = tid + k * NTHREADS;
+                if (interior) {
+                    const bool live = (k + 1 < NTASK || tid + k * NTHREADS < TASKS) &&
+                                      (FULL || g * GROUP + (tid + k * NTHREADS) / (RH * 16) < B);
+                    if (live) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(gbase + voff[k]);
+#pragma unroll
+                        for (int d = 0; d < WDW; ++d) win[k][d] = src[d];
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < WDW; ++d) win[k][d] = 0u;
+                    }
+                    continue;
+                }
+                const int q = tid_l + k * NTHREADS;
                 const int bit = g * GROUP + q / (RH * 16);
                 const int rem = q % (RH * 16);
                 const int row = rem >> 4, cg = rem & 15;
                 if (q < TASKS && bit < B) {
                     const PIX *plane = img + (int64_t)bit * a.bit_stride + (int64_t)z * a.z_stride;
                     const int gy = y0 - R + row, gx = x0 + 4 * cg - RA;
-                    if (interior) {
-                        const uint32_t *src =
-                            reinterpret_cast<const uint32_t *>(plane + (int64_t)gy * W + gx);
-#pragma unroll
-                        for (int d = 0; d < WDW; ++d) win[k][d] = src[d];
-                    } else {
+                    {
                         // border tiles only: keep the reflection arithmetic inside
                         // this branch (the compiler otherwise hoists and runs it
                         // for every tile)
@@ -595,7 +647,7 @@ decode_kernel(const DecodeArgs a)
                         af[ks] = *reinterpret_cast<const u32x4 *>(
                             lds_a + ((size_t)(ct + (lane & 31)) * MAXB +
                                      8 * ((2 * ks + half) ^ a_swz)) * 2);
-#if MF_TT_SEQ
+                    if constexpr (tiles_in_sequence(MAXB)) {
                     // one pixel tile at a time: 16 accumulator registers instead
                     // of 32; with three or four waves per SIMD the other waves
                     // cover the MFMA latency
@@ -637,7 +689,7 @@ decode_kernel(const DecodeArgs a)
                         }
                         st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
                     }
-#else
+                    } else {
                     // both pixel tiles first, so the second chain of MFMAs
                     // runs under the first tile's epilogue
                     f32x16 acc[2];
@@ -689,7 +741,7 @@ decode_kernel(const DecodeArgs a)
                         }
                         st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
                     }
-#endif
+                    }
                 }
             }
 
@@ -788,9 +840,9 @@ int launch(DecodeArgs &a, hipStream_t stream)
 
     const size_t hs_bytes = (size_t)GROUP * RH * TW * sizeof(HT);
     const size_t per_word = (size_t)MAXB * 2 + 8;
-    // two workgroups per CU (160 KB of LDS): the second wave on every SIMD is
-    // what overlaps one wave's MFMA chain with the other's key reduction
-    const size_t budget = 80 * 1024;
+    // as many workgroups per CU as the register budget allows waves per SIMD
+    // (160 KB of LDS shared between them)
+    const size_t budget = (size_t)160 * 1024 / (waves_per_simd(MAXB, UNI) * 4 / NWAVES);
     int chunk = (int)((budget - hs_bytes - 384) / per_word) & ~31;
     if (chunk >= a.Npad) {
         chunk = a.Npad;
@@ -845,7 +897,7 @@ template <typename PIX, int R>
 int dispatch_bits(DecodeArgs &a, hipStream_t s)
 {
     if (a.B <= 16) return dispatch_kind<PIX, R, 16, MF_PPT16>(a, s);
-    return dispatch_kind<PIX, R, 32, 2>(a, s);
+    return dispatch_kind<PIX, R, 32, MF_PPT32>(a, s);
 }
 
 template <typename PIX>
@@ -1091,6 +1143,11 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     a.fast_ok = image_dtype == MF_DTYPE_F32 ||
                 (!(W & 1) && !((img_bit_stride | img_z_stride) & 1) &&
                  !(reinterpret_cast<uintptr_t>(image) & 3));
+    // interior tiles address a task's window by a 32-bit byte offset inside a
+    // group of GROUP bit planes
+    if (img_bit_stride < 0 ||
+        ((int64_t)GROUP * img_bit_stride + (int64_t)64 * W + 64) * 4 >= ((int64_t)1 << 32))
+        a.fast_ok = 0;
     a.cbt = reinterpret_cast<const unsigned char *>(codebook_table);
     a.off_a = h.off_a; a.off_mask = h.off_mask; a.off_v = h.off_v; a.off_hn = h.off_hn;
     a.off_v64 = h.off_v64;

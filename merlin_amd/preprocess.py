@@ -173,15 +173,17 @@ def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
 
 
 def matlab_gauss2D(shape=(3, 3), sigma=0.5) -> np.ndarray:
-    """merlin/util/matlab.py:11-24: MATLAB's fspecial('gaussian', shape, sigma)."""
-    m, n = [(ss - 1.) / 2. for ss in shape]
-    y, x = np.ogrid[-m:m + 1, -n:n + 1]
-    h = np.exp(-(x * x + y * y) / (2. * sigma * sigma))
-    h[h < np.finfo(h.dtype).eps * h.max()] = 0
-    sumh = h.sum()
-    if sumh != 0:
-        h /= sumh
-    return h
+    """MATLAB's fspecial('gaussian', shape, sigma) (merlin/util/matlab.py:11-24):
+    a Gaussian sampled on the window's centred integer grid, entries below
+    eps * max dropped, normalised to unit sum."""
+    rows, cols = shape
+    dy = np.arange(rows, dtype=np.float64)[:, None] - (rows - 1.0) / 2.0
+    dx = np.arange(cols, dtype=np.float64)[None, :] - (cols - 1.0) / 2.0
+    window = np.exp(-(dx * dx + dy * dy) / (2.0 * sigma * sigma))
+    window = np.where(window < np.finfo(np.float64).eps * window.max(),
+                      0.0, window)
+    total = window.sum()
+    return window / total if total != 0 else window
 
 
 def calculate_projectors(windowSize: int, sigmaG: float) -> list:
