@@ -852,7 +852,10 @@ int launch(DecodeArgs &a, hipStream_t stream)
         chunk = ((a.Npad / 32 + n_chunks - 1) / n_chunks) * 32;
     }
     a.chunk = chunk;
-    const size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * sizeof(float);
+    size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * sizeof(float);
+#ifdef MF_LDS_MIN   // development: fewer workgroups per CU (room for other streams' kernels)
+    if (lds < MF_LDS_MIN) lds = MF_LDS_MIN;
+#endif
 
     const int cus = mf::device_cu_count();
     // far more workgroups than resident slots: the dispatcher balances the

@@ -60,6 +60,9 @@ class Decode(object):
         self.outputDirectory = outputDirectory
         # overlap=False: every stage of run_fovs on one stream (measurement)
         self.overlap = bool(overlap)
+        # depth of the run_fovs pipeline (see there)
+        self.decodeAhead = 1
+        self.frameLag = 2
 
     def get_codebook(self):
         return self._codebook
@@ -228,32 +231,39 @@ class Decode(object):
                 with torch.cuda.device(dev):
                     self._lbl = torch.cuda.Stream(dev)
             lbl = self._lbl
-        decoded = None      # (vol, labels pending, fov): stage 1 queued
-        tabled = None       # (vol, frame pending, fov): stage 2 queued
+        from collections import deque
+        decoded = deque()   # (vol, labels pending, fov): stage 1 queued
+        tabled = deque()    # (vol, frame pending, fov): stage 2 queued
+
+        def table(d):
+            pending = self._enqueue_table(d[0], d[1], side, typed, xy64)
+            tabled.append((d[0], pending, d[2]))
 
         def finish(t):
             return self._finish_fov(t[1], t[0], t[2], globalAligner,
                                     zPositions, database), t[0]
 
+        # The host blocks twice per FOV: on the region counts that size FOV
+        # k's tables (inherent) and on FOV j's frame rows.  decodeAhead decode
+        # kernels are queued beyond the FOV whose counts are awaited and
+        # frameLag FOVs may have their tables and rows in flight, so neither
+        # wait leaves the main stream without a queued decode kernel.
+        ahead = self.decodeAhead if side is not None else 1
+        lag = self.frameLag if side is not None else 1
         for k, stack in enumerate(imageStacks):
             fov = k if fovs is None else fovs[k]
-            nxt = self._enqueue_decode(stack, scaleFactors, backgrounds,
-                                       lbl) + (fov,)
-            if decoded is not None:
-                pending = self._enqueue_table(decoded[0], decoded[1], side,
-                                              typed, xy64)
-                if tabled is not None:
-                    yield finish(tabled)
-                tabled = (decoded[0], pending, decoded[2])
-            decoded = nxt
-        if decoded is not None:
-            pending = self._enqueue_table(decoded[0], decoded[1], side,
-                                              typed, xy64)
-            if tabled is not None:
-                yield finish(tabled)
-            tabled = (decoded[0], pending, decoded[2])
-        if tabled is not None:
-            yield finish(tabled)
+            decoded.append(self._enqueue_decode(stack, scaleFactors,
+                                                backgrounds, lbl) + (fov,))
+            if len(decoded) > ahead:
+                table(decoded.popleft())
+            while len(tabled) > lag:
+                yield finish(tabled.popleft())
+        while decoded:
+            table(decoded.popleft())
+            while len(tabled) > lag:
+                yield finish(tabled.popleft())
+        while tabled:
+            yield finish(tabled.popleft())
 
     def run_fovs_sharded(self, stackProvider, scaleFactors, backgrounds, fovs,
                          rank=None, world=None, group=None,
