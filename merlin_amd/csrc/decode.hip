@@ -60,6 +60,7 @@ constexpr double TIE_D2_MARGIN = 1.0e-4;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // Device codebook table built by mf_codebook_prepare (offsets in bytes from
 // the start of the blob, 256-byte aligned; a function of N and B only).
@@ -184,17 +185,29 @@ __device__ __forceinline__ f32x2 div_by_recip2(f32x2 n, f32x2 d, f32x2 r)
 #ifndef MF_D2_FMA
 #define MF_D2_FMA 1
 #endif
+#ifndef MF_HPASS_DOT2
+#define MF_HPASS_DOT2 1
+#endif
+// two row-sum buffers in LDS, used alternately by the groups of bits: one
+// barrier per group instead of two (the horizontal pass of group g+1 may start
+// while other waves still read group g)
+#ifndef MF_HS_DOUBLE
+#define MF_HS_DOUBLE 0   // measured: no gain (1.191 vs 1.192 ms), twice the LDS
+#endif
+constexpr int HS_BUFFERS = MF_HS_DOUBLE ? 2 : 1;
 // Per bit-count class (<= 16 bits / <= 32 bits): pixel rows per thread, waves
 // per SIMD the register budget is set for, and whether the two 32-pixel
 // accumulator tiles of a row are worked one after the other (16 registers
 // instead of 32).  Measured per 7-z FOV (16 bits, 140 codewords): 4 rows x 2
 // waves 1.40 ms, 4 rows x 3 waves sequential 1.22, 2 rows x 4 waves
-// sequential 1.20.
+// sequential 1.20; with the dot2 horizontal pass 1.16 and 1.19, and the
+// three-wave kernel leaves room on the CUs for the region-table kernels of the
+// previous FOV (1.93 vs 2.06 ms per FOV in the pipelined loop).
 #ifndef MF_PPT16
-#define MF_PPT16 2
+#define MF_PPT16 4
 #endif
 #ifndef MF_WPS16
-#define MF_WPS16 4
+#define MF_WPS16 3
 #endif
 #ifndef MF_SEQ16
 #define MF_SEQ16 1
@@ -265,10 +278,10 @@ decode_kernel(const DecodeArgs a)
     constexpr int NTASK = (TASKS + NTHREADS - 1) / NTHREADS;
     constexpr int NG = MAXB / GROUP;
     constexpr int KS = MAXB / 16;                  // MFMA k-steps
-    constexpr size_t HS_BYTES = (size_t)GROUP * RH * TW * sizeof(HT);
+    constexpr size_t HS_BYTES = (size_t)HS_BUFFERS * GROUP * RH * TW * sizeof(HT);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    HT *hs = reinterpret_cast<HT *>(smem);                           // [GROUP][RH][TW]
+    HT *hs0 = reinterpret_cast<HT *>(smem);                          // [buffers][GROUP][RH][TW]
     unsigned char *lds_a = smem + HS_BYTES;                          // bf16 [chunk][MAXB]
     float *lds_v = reinterpret_cast<float *>(lds_a + (size_t)a.chunk * MAXB * 2);
     float *lds_hn = lds_v + a.chunk;
@@ -405,13 +418,39 @@ decode_kernel(const DecodeArgs a)
         };
 
         // ---- horizontal pass from the register windows into LDS ----
-        auto hpass = [&]() {
+        auto hpass = [&](int g) {
+            HT *hs = hs0 + (g % HS_BUFFERS) * (GROUP * RH * TW);
 #pragma unroll
             for (int k = 0; k < NTASK; ++k) {
                 const int q = tid + k * NTHREADS;
                 if (q < TASKS) {
                     u32x4 v;
                     if constexpr (IS_U16) {
+                        if constexpr (MF_HPASS_DOT2 && R > 0) {
+                        // (R = 0: the single tap is 65536, no 16-bit operand)
+                        // every window dword holds two pixels: one
+                        // v_dot2_u32_u16 per dword with the pair of taps that
+                        // falls on it (a zero tap outside the kernel); exact
+                        // u32 sums as before (taps sum to 65536, pixels < 2^16)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = RA + j;
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int d = 0; d < WDW; ++d) {
+                                const int o0 = 2 * d - c, o1 = 2 * d + 1 - c;   // tap offsets
+                                const bool in0 = o0 >= -R && o0 <= R, in1 = o1 >= -R && o1 <= R;
+                                if (in0 || in1) {
+                                    const uint32_t t0 = in0 ? a.kfix[R + (o0 < 0 ? -o0 : o0)] : 0u;
+                                    const uint32_t t1 = in1 ? a.kfix[R + (o1 < 0 ? -o1 : o1)] : 0u;
+                                    acc = __builtin_amdgcn_udot2(
+                                        __builtin_bit_cast(u16x2, win[k][d]),
+                                        __builtin_bit_cast(u16x2, t0 | (t1 << 16)), acc, false);
+                                }
+                            }
+                            v[j] = acc;
+                        }
+                        } else {
                         uint32_t p[NW];
 #pragma unroll
                         for (int d = 0; d < WDW; ++d) {
@@ -426,6 +465,7 @@ decode_kernel(const DecodeArgs a)
                             for (int i = 1; i <= R; ++i)
                                 acc += __umul24(a.kfix[R + i], p[c - i] + p[c + i]);
                             v[j] = acc;
+                        }
                         }
                     } else {
 #pragma unroll
@@ -450,8 +490,9 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g * GROUP < B) {
-                hpass();
+                hpass(g);
                 __syncthreads();
+                const HT *hs = hs0 + (g % HS_BUFFERS) * (GROUP * RH * TW);
                 if (g + 1 < NG && (g + 1) * GROUP < B) prefetch(g + 1);
                 // ---- vertical pass for this thread's PPT pixels ----
 #pragma unroll
@@ -523,7 +564,7 @@ decode_kernel(const DecodeArgs a)
                     }
                     MF_FENCE();
                 }
-                __syncthreads();   // hs is rewritten by the next group
+                if constexpr (HS_BUFFERS == 1) __syncthreads();   // hs is rewritten by the next group
             } else {
 #pragma unroll
                 for (int i = 0; i < GROUP; ++i)
@@ -612,9 +653,16 @@ decode_kernel(const DecodeArgs a)
                         pk[s][ks][d] = __builtin_amdgcn_perm(__float_as_uint(r[2 * d + 1]),
                                                              __float_as_uint(r[2 * d]), 0x07060302u);
                     if (s < 2) {
+                        // residual after the bf16 truncation (exact), two
+                        // elements per v_pk_add_f32
 #pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            r[j] = r[j] - __uint_as_float(__float_as_uint(r[j]) & 0xffff0000u);
+                        for (int j = 0; j < 16; j += 2) {
+                            const f32x2 hi = {__uint_as_float(__float_as_uint(r[j]) & 0xffff0000u),
+                                              __uint_as_float(__float_as_uint(r[j + 1]) & 0xffff0000u)};
+                            const f32x2 lo = (f32x2){r[j], r[j + 1]} - hi;
+                            r[j] = lo.x;
+                            r[j + 1] = lo.y;
+                        }
                     }
                 }
 #pragma unroll
@@ -838,7 +886,7 @@ int launch(DecodeArgs &a, hipStream_t stream)
     if (nt > INT32_MAX) return mf::fail(MF_EUNSUPPORTED, "too many tiles");
     a.n_tiles = (int)nt;
 
-    const size_t hs_bytes = (size_t)GROUP * RH * TW * sizeof(HT);
+    const size_t hs_bytes = (size_t)HS_BUFFERS * GROUP * RH * TW * sizeof(HT);
     const size_t per_word = (size_t)MAXB * 2 + 8;
     // as many workgroups per CU as the register budget allows waves per SIMD
     // (160 KB of LDS shared between them)
