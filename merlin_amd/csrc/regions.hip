@@ -434,21 +434,24 @@ emit_boundaries(const uint32_t *__restrict__ keys, int64_t n,
 // barcode, sorted stably.  In 2-D mode the plane is root / plane_px.
 __global__ void __launch_bounds__(NT)
 region_keys(const uint32_t *__restrict__ roots_sorted, const int32_t *__restrict__ offsets,
-            const int16_t *__restrict__ dec, int64_t n_reg, int plane_px, int conn3d,
-            uint32_t *__restrict__ keys, int32_t *__restrict__ idx)
+            const int16_t *__restrict__ dec, int64_t n_reg, int64_t n_pix, int plane_px,
+            int conn3d, uint32_t *__restrict__ keys, int64_t *__restrict__ span)
 {
     const int64_t j = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (j >= n_reg) return;
-    const uint32_t root = roots_sorted[offsets[j]];
+    const int32_t lo = offsets[j];
+    const int64_t hi = j + 1 < n_reg ? offsets[j + 1] : n_pix;
+    const uint32_t root = roots_sorted[lo];
     const uint32_t grp = conn3d ? 0u : root / (uint32_t)plane_px;
     keys[j] = grp * 32768u + (uint32_t)dec[root];
-    idx[j] = (int32_t)j;
+    // the sort carries the region's span in the pixel list along, so the
+    // statistics kernel starts from one load instead of a chain of three
+    span[j] = (int64_t)lo | (hi << 32);
 }
 
 struct StatsArgs {
     const int32_t *pix;      // sorted by root, raster order inside a region
-    const int32_t *offsets;  // [n_regions] first entry of each region, root order
-    const int32_t *order;    // [n_regions] region emitted as row r
+    const int64_t *span;     // [n_regions] first | one-past-last << 32 of row r's pixels
     int64_t tr_p;
     int64_t n_pix, n_reg;
     const int16_t *dec;
@@ -487,6 +490,8 @@ __device__ __forceinline__ void group_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// WIDE: more than 16 bits per codeword (a lane then also carries bit sub + 16)
+template <bool WIDE>
 __global__ void __launch_bounds__(NT)
 region_stats(const StatsArgs a)
 {
@@ -496,9 +501,8 @@ region_stats(const StatsArgs a)
     StagePix *st = stage[threadIdx.x / RSUB];
     const bool valid = r < a.n_reg;
     if (!valid) r = a.n_reg - 1;          // keep whole groups alive
-    const int64_t j = a.order[r];
-    const int64_t i0 = a.offsets[j];
-    const int64_t i1 = j + 1 < a.n_reg ? a.offsets[j + 1] : a.n_pix;
+    const int64_t sp_ = a.span[r];
+    const int64_t i0 = sp_ & 0xffffffffll, i1 = sp_ >> 32;
     const int n = (int)(i1 - i0);
     const int plane = a.H * a.W;
     const int first = a.pix[i0];
@@ -510,14 +514,18 @@ region_stats(const StatsArgs a)
     float mmax = -INFINITY;
     float s0 = 0.0f, stm0 = 0.0f, mn0 = INFINITY;     // bit sub
     float s1 = 0.0f, stm1 = 0.0f, mn1 = INFINITY;     // bit sub + 16
-    const bool has0 = sub < a.B, has1 = sub + RSUB < a.B;
+    const bool has0 = sub < a.B, has1 = WIDE && sub + RSUB < a.B;
     const int64_t boff0 = (int64_t)sub * a.tr_b, boff1 = (int64_t)(sub + RSUB) * a.tr_b;
     int myp = first;
     float mym = 0.0f;
+    // this lane's pixel of the next chunk is fetched one chunk ahead
+    int nxp = i0 + sub < i1 ? a.pix[i0 + sub] : first;
     for (int64_t base = i0; base < i1; base += RSUB) {
         const int cnt = (int)min((int64_t)RSUB, i1 - base);
+        const int curp = nxp;
+        if (base + RSUB + sub < i1) nxp = a.pix[base + RSUB + sub];
         if (sub < cnt) {
-            myp = a.pix[base + sub];
+            myp = curp;
             mym = a.mag[myp];
             const double myd = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[myp]
                                           : (double)reinterpret_cast<const float *>(a.dist)[myp];
@@ -537,7 +545,7 @@ region_stats(const StatsArgs a)
         for (int k = 0; k < RSUB; ++k) {
             const int64_t off = st[k < cnt ? k : 0].toff;
             t0[k] = has0 && k < cnt ? a.traces[off + boff0] : 0.0f;
-            t1[k] = has1 && k < cnt ? a.traces[off + boff1] : 0.0f;
+            t1[k] = WIDE && has1 && k < cnt ? a.traces[off + boff1] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < RSUB; ++k) {
@@ -549,11 +557,14 @@ region_stats(const StatsArgs a)
                 dsum += d;
                 dmin = fmin(dmin, d);
                 s0 = s0 + t0[k];
-                s1 = s1 + t1[k];
+                if constexpr (WIDE) s1 = s1 + t1[k];
                 if (want_tm) {
-                    const float tm0 = t0[k] * m, tm1 = t1[k] * m;
+                    const float tm0 = t0[k] * m;
                     stm0 = stm0 + tm0; mn0 = fminf(mn0, tm0);
-                    stm1 = stm1 + tm1; mn1 = fminf(mn1, tm1);
+                    if constexpr (WIDE) {
+                        const float tm1 = t1[k] * m;
+                        stm1 = stm1 + tm1; mn1 = fminf(mn1, tm1);
+                    }
                 }
             }
         }
@@ -678,8 +689,8 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
                                   (unsigned)pl.root_bits);
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
     e = rocprim::radix_sort_pairs<RegionSortConfig>(nullptr, t4, (uint32_t *)nullptr,
-                                                    (uint32_t *)nullptr, (int32_t *)nullptr,
-                                                    (int32_t *)nullptr, nr, 0u,
+                                                    (uint32_t *)nullptr, (int64_t *)nullptr,
+                                                    (int64_t *)nullptr, nr, 0u,
                                                     (unsigned)pl.region_key_bits);
     if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
     pl.temp_bytes = t2 > t4 ? t2 : t4;
@@ -694,8 +705,8 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     pl.offsets = off; off += align_up((nr + 1) * 4);
     pl.rkeys_a = off; off += align_up(nr * 4);
     pl.rkeys_b = off; off += align_up(nr * 4);
-    pl.ridx_a = off; off += align_up(nr * 4);
-    pl.ridx_b = off; off += align_up(nr * 4);
+    pl.ridx_a = off; off += align_up(nr * 8);
+    pl.ridx_b = off; off += align_up(nr * 8);
     pl.chunks = off; off += align_up((size_t)pl.vol_chunks * 4);
     pl.temp = off; off += align_up(pl.temp_bytes);
     pl.total = off;
@@ -1115,8 +1126,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     int32_t *offsets = reinterpret_cast<int32_t *>(ws + pl.offsets);
     uint32_t *rkeys_a = reinterpret_cast<uint32_t *>(ws + pl.rkeys_a);
     uint32_t *rkeys_b = reinterpret_cast<uint32_t *>(ws + pl.rkeys_b);
-    int32_t *ridx_a = reinterpret_cast<int32_t *>(ws + pl.ridx_a);
-    int32_t *ridx_b = reinterpret_cast<int32_t *>(ws + pl.ridx_b);
+    int64_t *ridx_a = reinterpret_cast<int64_t *>(ws + pl.ridx_a);
+    int64_t *ridx_b = reinterpret_cast<int64_t *>(ws + pl.ridx_b);
     int32_t *chunks = reinterpret_cast<int32_t *>(ws + pl.chunks);
     void *temp = ws + pl.temp;
     size_t tb = pl.temp_bytes;
@@ -1143,7 +1154,7 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     {
         const unsigned gq = (unsigned)((n_regions + NT - 1) / NT);
         hipLaunchKernelGGL(region_keys, dim3(gq), dim3(NT), 0, s, keys_b, offsets, decoded,
-                           n_regions, H * W, conn3d, rkeys_a, ridx_a);
+                           n_regions, n_pixels, H * W, conn3d, rkeys_a, ridx_a);
     }
     tb = pl.temp_bytes;
     MF_HIP_CHECK(rocprim::radix_sort_pairs<RegionSortConfig>(
@@ -1151,14 +1162,17 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
         (unsigned)pl.region_key_bits, s));
     // 5. per-region rows
     StatsArgs a;
-    a.pix = pix_b; a.offsets = offsets; a.order = ridx_b; a.n_pix = n_pixels; a.n_reg = n_regions;
+    a.pix = pix_b; a.span = ridx_b; a.n_pix = n_pixels; a.n_reg = n_regions;
     a.dec = decoded; a.mag = magnitudes; a.dist = distances;
     a.dist_f64 = dist_dtype == MF_DTYPE_F64;
     a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride; a.tr_p = tr_pix_stride;
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.conn3d = conn3d;
     a.rec = rec; a.inten = inten; a.mean_tm = mean_tm; a.min_tm = min_tm;
     const unsigned gr = (unsigned)((n_regions * RSUB + NT - 1) / NT);
-    hipLaunchKernelGGL(region_stats, dim3(gr), dim3(NT), 0, s, a);
+    if (B > RSUB)
+        hipLaunchKernelGGL(region_stats<true>, dim3(gr), dim3(NT), 0, s, a);
+    else
+        hipLaunchKernelGGL(region_stats<false>, dim3(gr), dim3(NT), 0, s, a);
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
 }
