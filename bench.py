@@ -152,8 +152,8 @@ def codebook_configs(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-pipeline', action='store_true')
     ap.add_argument('--no-preprocess', action='store_true')
@@ -369,12 +369,18 @@ def main():
         p1.record()
         torch.cuda.synchronize(dev)
         ms_frame = p0.elapsed_time(p1) / 3 / n_frames
-        pre_bytes = (34 * 20 + 40) * H * W
+        # bytes this implementation must move (646 B/px), and the
+        # r01 figure (every iteration 34 B + an initialisation pass: 720 B/px)
+        from merlin_amd.preprocess import algorithmic_bytes_per_pixel
+        pre_bytes = algorithmic_bytes_per_pixel(20) * H * W
+        pre_bytes_r01 = (34 * 20 + 40) * H * W
         pre_line = {'ms_per_frame': ms_frame, 'Mpx_per_s': H * W / ms_frame / 1e3,
                     'ms_per_fov': ms_frame * B * Z, 'dtype': 'f64',
                     'roofline': {'bound': 'hbm', 'achieved': pre_bytes / ms_frame / 1e6,
                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                 'frac': pre_bytes / ms_frame / 1e6 / HBM_PEAK_GBS},
+                                 'frac': pre_bytes / ms_frame / 1e6 / HBM_PEAK_GBS,
+                                 'bytes_per_px': pre_bytes // (H * W),
+                                 'frac_r01_bytes': pre_bytes_r01 / ms_frame / 1e6 / HBM_PEAK_GBS},
                     'note': 'camera frames (offset 2000 + the synthetic FOV) -> uint16 stack + '
                             'pixel histogram for the {} frames of one FOV'.format(n_frames)}
         del frames, pre

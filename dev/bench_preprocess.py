@@ -3,10 +3,9 @@ time per 2048 x 2048 camera frame by batch size, against the traffic roofline.
 
     python3 dev/bench_preprocess.py [--images 16] [--batches 1,2,4,7] [--cpu]
 
-Algorithmic bytes per pixel and image: per iteration
-the fused kernel reads J1, J2, J3 (24) + the uint16 observed image (2) and
-writes J1' (8): 34 B; x 20 iterations + high-pass (4) + init (26) + hand-over
-(10) = 720 B/px.  (MF_LR_SPLIT=1, the two-launch iteration: 74 B.)  Prints one
+Algorithmic bytes per pixel and image (DESIGN.md section 4.5,
+merlin_amd.preprocess.algorithmic_bytes_per_pixel): 646 B/px at 20 iterations
+(r01: 720, every iteration 34 B plus an initialisation pass).  Prints one
 JSON line per batch size.
 """
 import argparse
@@ -53,8 +52,7 @@ def main():
     a = ap.parse_args()
     H = W = a.size
     frames = camera_frames(a.images, H, W)
-    per_iter = 74 if os.environ.get('MF_LR_SPLIT') else 34
-    bytes_px = per_iter * a.iterations + 40
+    bytes_px = pp.algorithmic_bytes_per_pixel(a.iterations)
     cpu = None
     if a.cpu:
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))

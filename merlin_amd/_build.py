@@ -22,6 +22,12 @@ SOURCES = ['common.cpp', 'decode.hip', 'regions.hip', 'preprocess.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-ffp-contract=off', '-I' + INCLUDE, '-I' + CSRC,
          '-Wno-unused-result']
+# Per-file extras.  preprocess.hip: the float64 filter chains are long runs of
+# dependent multiply / add; the default scheduler (minimum registers at the
+# occupancy bound) leaves every instruction waiting on the one before it, the
+# ILP-first strategy interleaves the independent chains (two columns per lane,
+# products ahead of sums) and needs fewer registers doing so.
+FILE_FLAGS = {'preprocess.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
 
 
 def _hipcc():
@@ -43,8 +49,8 @@ def _compile(src):
     deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'common.h'),
             os.path.join(INCLUDE, 'merfish_hip.h'), os.path.abspath(__file__)]
     if _stale(obj, deps):
-        cmd = [_hipcc(), '-x', 'hip'] + FLAGS + ['-c', os.path.join(CSRC, src),
-                                                '-o', obj]
+        cmd = [_hipcc(), '-x', 'hip'] + FLAGS + FILE_FLAGS.get(src, []) \
+            + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for {}:\n{}'.format(src, r.stderr))

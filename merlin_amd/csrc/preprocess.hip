@@ -6,16 +6,18 @@
 // merlin/analysis/preprocess.py:114-140 (_preprocess_image + pixel histogram).
 //
 // The deconvolution is float64 like the reference and bound by memory traffic.
-// One launch per iteration (lr_fused_kernel): single-wave workgroups stream
-// 64-column strips through both blurs of the iteration, so that per pixel only
-// J1, J2, J3 and the observed image are read and the new J1 written (34 B);
-// the sums behind the acceleration parameter are reduced in a fixed order.
-// lr_stream_kernel (two launches per iteration through a stored ratio image,
-// 74 B) is the earlier form, kept behind MF_LR_SPLIT=1.
+// One launch per iteration: single-wave workgroups stream column strips (128
+// columns, two per lane; 64 when the image width is odd) through both blurs of
+// the iteration, so that per pixel only J1, J2, J3 and the observed image are
+// read and the new J1 written (34 B).  The sums behind the acceleration
+// parameter leave each strip as per-16-row partials and are added in a fixed
+// order by a one-block kernel between the iterations (lr_lambda_kernel): the
+// hand-off is a kernel boundary, and the result does not depend on how a frame
+// was cut into strip segments.
 //
 // Frames are processed `batch` at a time (one launch covers the batch; the
-// working set is 34 B/px per frame); large batches keep the chip filled to the
-// end of each launch.
+// working set is 26 B/px per frame); the segment height is chosen per launch so
+// that the strips fill whole rounds of the chip's wave slots (choose_segments).
 //
 // Built with -ffp-contract=off: every product and sum below rounds on its own,
 // as the non-FMA scalar path of OpenCV and numpy do.
@@ -23,6 +25,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
@@ -30,10 +33,8 @@
 namespace {
 
 constexpr int TW = 64;          // tile width = wave width
-#ifndef MF_LR_SEG
-#define MF_LR_SEG 128
-#endif
-constexpr int SEG = MF_LR_SEG;  // rows of one deconvolution strip segment
+constexpr int BH = 16;          // rows per block of lambda partial sums; segments are whole blocks
+constexpr int SEG_MIN_BLOCKS = 4;   // shortest strip segment: 64 rows
 constexpr int TH = 32;          // tile height: 4 waves x 8 rows
 constexpr int NT = 256;
 constexpr int ROWS_PER_WAVE = TH / 4;
@@ -73,35 +74,20 @@ __device__ __forceinline__ double make_y(double j1, double j2, double lam)
 struct LrArgs {
     const void *wi;          // observed image(s), u16 or f64 [n][HW]
     const double *j1, *j2;   // [n][HW]
-    const double *j3;        // fused kernel: the J before j2 (its buffer receives jnew)
-    const double *lam_prev;  // fused kernel: [n] lambda of the previous iteration
-    double *ratio;           // [n][HW]
-    double *jnew;            // = j2's buffer
-    double *t1;              // [n][HW], updated in place
+    const double *j3;        // the J before j2 (its buffer receives jnew)
+    double *jnew;
     const double *lam;       // [n] lambda of this iteration
-    double *lam_next;        // [n]
-    double *lam_trace;       // [n][trace_stride] or NULL: lambda used by iteration `iter`
-    int64_t trace_stride;
-    int iter;
-    double *partials;        // [n][tiles][2]
-    unsigned *counters;      // [n]
-    int H, W, tiles_x, tiles;
+    const double *lam_prev;  // [n] lambda of the previous iteration
+    double *partials;        // [n][nblk][tiles_x][2]
+    int H, W;
+    int jp;                  // row pitch of the J buffers, in doubles
+    int64_t js;              // frame stride of the J buffers, in doubles
+    int tiles_x;             // strips across the image
+    int nseg;                // segments a strip is cut into (each a whole number of blocks)
+    int nblk;                // blocks of BH rows per frame
+    int tiles;               // tiles_x * nseg
     Taps tp;
 };
-
-__device__ __forceinline__ double atomic_load_f64(const double *p)
-{
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __longlong_as_double((long long)v);
-}
-
-__device__ __forceinline__ void atomic_store_f64(double *p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
-                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // compile-time ordering of LDS accesses among the lanes of one wave
 __device__ __forceinline__ void lds_wave_order()
@@ -116,178 +102,34 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;       // lane 0 holds the total
 }
 
-// One wave streams a 64-column strip of SEG rows from top to bottom.  Per input
-// row: the wave's 64 + 2R values go through one LDS row for the row pass
-// (OpenCV RowFilter: s = k[0] S[0]; s += k[j] S[j], left to right), the row
-// sums of the last 2R + 1 rows live in a register ring, and the column pass
-// (SymmColumnFilter: centre, then k[R+j] (S[+j] + S[-j]) outwards) finishes
-// output row r - R.  No workgroup barrier (a workgroup is one wave), the next
-// row's loads are in flight while this one is filtered, and up to eight such
-// waves per SIMD hide what is left of the latency.
-//
-// UPDATE = false (lr_reblur): source Y = max(J1 + lambda (J1 - J2), 0) rebuilt on
-//   the fly; output ratio = wI / max(blur, eps) + eps       (deconvolve.py:112-122)
-// UPDATE = true  (lr_update): source = ratio; J1' = Y * blur, T1' = J1' - Y, and
-//   the tile's sums of T1' T1 and T1 T1; the LAST tile of the image to finish
-//   adds the tile partials in tile order and publishes the next lambda
-//   (no float atomics: identical from run to run)           (deconvolve.py:107-132)
-template <int R, int SEGT, int P, typename WT, bool UPDATE>
-__global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
+// A wave-uniform condition that must stay a branch: an empty volatile asm in
+// the conditional block keeps the compiler from turning the block into
+// per-lane selects (18 of them per row for the ring fill below).
+#define MF_UNIFORM_BRANCH() asm volatile("" ::: "memory")
+
+// The strip's sums over one block of BH output rows -> partials.  Blocks are
+// aligned to image rows, so the set of partials (and the order lr_lambda_kernel
+// adds them in) is the same however the frame is cut into segments.
+__device__ __forceinline__ void store_partial(const LrArgs &a, int img, int blk, int sx, int lane,
+                                              double s_ab, double s_bb)
 {
-    __shared__ double srow[TW + 2 * R + 2];
-    const int t = xcd_tile(a.tiles);
-    if (t < 0) return;
-    const int img = blockIdx.y;
-    const int lane = threadIdx.x;
-    const int H = a.H, W = a.W;
-    const int64_t base = (int64_t)img * H * W;
-    const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * SEGT;
-    const int rows_out = min(SEGT, H - y0);
-    const double lam = a.lam[img];
-    const double *j1 = a.j1 + base, *j2 = a.j2 + base;
-    const double *ratio = a.ratio + base;
-    const WT *wi = reinterpret_cast<const WT *>(a.wi) + base;
-    const double *t1 = a.t1 + base;
-    // source columns: lane L holds x0 - R + L, lanes < 2R also x0 - R + 64 + L
-    const int cm = clampi(x0 - R + lane, 0, W - 1);
-    const int ch = clampi(x0 - R + TW + lane, 0, W - 1);
-    const bool has_halo = lane < 2 * R;
-    const int gx = x0 + lane;
-    const int cg = min(gx, W - 1);
-
-    // P source rows and P output rows' operands in flight, in fixed registers
-    // (the row loop is unrolled P times so that no load target is ever moved)
-    double m0[P], m1[P], h0[P], h1[P];
-    double e0[P], e1[P], e2[P];
-    WT w0[P];            // raw observed value: converted where it is used, not where it lands
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-        m0[u] = m1[u] = h0[u] = h1[u] = e0[u] = e1[u] = e2[u] = 0.0;
-        w0[u] = (WT)0;
+    s_ab = wave_sum(s_ab);
+    s_bb = wave_sum(s_bb);
+    if (lane == 0) {
+        double *pp = a.partials + (((int64_t)img * a.nblk + blk) * a.tiles_x + sx) * 2;
+        pp[0] = s_ab;
+        pp[1] = s_bb;
     }
-    // rows past either end of the strip (pipeline warm-up and drain) are
-    // redirected to rows the wave reads anyway: an L1/L2 hit, no fabric traffic
-    auto fetch = [&](int u, int r) {
-        const int64_t row = (int64_t)clampi(y0 + min(r, rows_out + R - 1), 0, H - 1) * W;
-        if constexpr (UPDATE) {
-            m0[u] = ratio[row + cm];
-            if (has_halo) h0[u] = ratio[row + ch];
-        } else {
-            m0[u] = j1[row + cm];
-            m1[u] = j2[row + cm];
-            if (has_halo) { h0[u] = j1[row + ch]; h1[u] = j2[row + ch]; }
-        }
-    };
-    auto fetch_epilogue = [&](int u, int ro) {
-        const int64_t p = (int64_t)(y0 + clampi(ro, 0, rows_out - 1)) * W + cg;
-        if constexpr (UPDATE) { e0[u] = j1[p]; e1[u] = j2[p]; e2[u] = t1[p]; }
-        else w0[u] = wi[p];
-    };
+}
 
-    double ring[2 * R + 1];
-#pragma unroll
-    for (int j = 0; j <= 2 * R; ++j) ring[j] = 0.0;
-    double s_ab = 0.0, s_bb = 0.0;
-
-    // Straight-line software pipeline: every fetch is unconditional (row
-    // indexes clamp, so rows past the strip only cost a wasted load) and the
-    // trip count is padded to a multiple of P, so that no load target is copied
-    // or waited for before its row is consumed.
-    const int r_end = rows_out + R;
-#pragma unroll
-    for (int u = 0; u < P; ++u) { fetch(u, -R + u); fetch_epilogue(u, -2 * R + u); }
-    for (int rb = -R; rb < r_end; rb += P) {
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-            const int r = rb + u;
-            double vm, vh;
-            if constexpr (UPDATE) { vm = m0[u]; vh = h0[u]; }
-            else { vm = make_y(m0[u], m1[u], lam); vh = make_y(h0[u], h1[u], lam); }
-            const double c0 = e0[u], c1 = e1[u], c2 = e2[u];
-            const WT cw = w0[u];
-            fetch(u, r + P);
-            fetch_epilogue(u, r + P - R);
-            // one wave per workgroup: LDS operations of a wave execute in
-            // order, so the row only needs the compiler to keep them in order
-            // (a __syncthreads() would also wait for every global load in flight)
-            lds_wave_order();
-            srow[lane] = vm;
-            if (has_halo) srow[TW + lane] = vh;
-            lds_wave_order();
-            double s = a.tp.k[0] * srow[lane];
-#pragma unroll
-            for (int j = 1; j <= 2 * R; ++j) s = s + a.tp.k[j] * srow[lane + j];
-#pragma unroll
-            for (int j = 0; j < 2 * R; ++j) ring[j] = ring[j + 1];
-            ring[2 * R] = s;
-            const int ro = r - R;
-            double o = a.tp.k[R] * ring[R];
-#pragma unroll
-            for (int j = 1; j <= R; ++j) o = o + a.tp.k[R + j] * (ring[R + j] + ring[R - j]);
-            const bool ok = ro >= 0 && ro < rows_out && gx < W;
-            const int64_t p = base + (int64_t)(y0 + ro) * W + gx;
-            if constexpr (UPDATE) {
-                const double y = make_y(c0, c1, lam);
-                const double jn = y * o;             // np.multiply(Y, imR, out=J1)
-                const double tn = jn - y;            // np.subtract(J1, Y, out=T1)
-                if (ok) {
-                    a.jnew[p] = jn;
-                    a.t1[p] = tn;
-                }
-                s_ab = s_ab + (ok ? tn * c2 : 0.0);  // cv2.multiply(T1, T2) summed
-                s_bb = s_bb + (ok ? c2 * c2 : 0.0);
-            } else {
-                const double rbl = o < EPS ? EPS : o;              // np.clip(reblurred, eps, None)
-                if (ok) a.ratio[p] = (double)cw / rbl + EPS;       // cv2.divide; imR += eps
-            }
-        }
-    }
-    if constexpr (UPDATE) {
-        // Tile partials cross to the reducing wave as 8-byte agent-scope
-        // (sc1) stores and loads with the storing wave's vmcnt(0) before its
-        // ticket: no L2 write-back / invalidate per tile.
-        s_ab = wave_sum(s_ab);
-        s_bb = wave_sum(s_bb);
-        unsigned ticket = 0;
-        if (lane == 0) {
-            double *pp = a.partials + ((int64_t)img * a.tiles + t) * 2;
-            atomic_store_f64(pp, s_ab);
-            atomic_store_f64(pp + 1, s_bb);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ticket = atomicAdd(a.counters + img, 1u);
-        }
-        ticket = __shfl(ticket, 0, 64);
-        if (ticket != (unsigned)a.tiles - 1u) return;
-        // last tile of this image: lane i adds tiles i, i + 64, ... in order
-        const double *pp = a.partials + (int64_t)img * a.tiles * 2;
-        double ab = 0.0, bb = 0.0;
-        constexpr int U = 8;
-        for (int i0 = lane; i0 < a.tiles; i0 += 64 * U) {
-            double va[U], vb[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + 64 * u;
-                va[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i) : 0.0;
-                vb[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i + 1) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (i0 + 64 * u < a.tiles) { ab = ab + va[u]; bb = bb + vb[u]; }
-            }
-        }
-        ab = wave_sum(ab);
-        bb = wave_sum(bb);
-        if (lane == 0) {
-            double l = ab / (bb + EPS);                   // deconvolve.py:110
-            l = 1.0 < l ? 1.0 : l;                        // min(l, 1)
-            l = 0.0 > l ? 0.0 : l;                        // max(., 0)
-            // the reference only starts accelerating at its third iteration
-            if (a.iter + 1 <= 1) l = 0.0;
-            a.lam_next[img] = l;
-            if (a.lam_trace) a.lam_trace[(int64_t)img * a.trace_stride + a.iter + 1] = l;
-            a.counters[img] = 0u;
-        }
-    }
+// tile -> strip column sx, first image row y0 and row count of its segment
+__device__ __forceinline__ void tile_rows(const LrArgs &a, int t, int &sx, int &y0, int &rows_out)
+{
+    sx = t % a.tiles_x;
+    const int k = t / a.tiles_x;
+    const int b0 = (int)((int64_t)k * a.nblk / a.nseg), b1 = (int)((int64_t)(k + 1) * a.nblk / a.nseg);
+    y0 = b0 * BH;
+    rows_out = min(b1 * BH, a.H) - y0;
 }
 
 // ---- fused iteration -------------------------------------------------------
@@ -315,7 +157,7 @@ __global__ void __launch_bounds__(64) lr_stream_kernel(const LrArgs a)
 // there missed L2 too often: 384 waves per XCD stream more than its 4 MB
 // between the two uses), so every loaded register is dead within the row it is
 // consumed in.
-template <int R, int SEGT, int P, typename WT>
+template <int R, int P, typename WT>
 __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 {
     constexpr int OUTW = TW - 4 * R;
@@ -329,12 +171,14 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
     const int img = blockIdx.y;
     const int lane = threadIdx.x;
     const int H = a.H, W = a.W;
-    const int64_t base = (int64_t)img * H * W;
-    const int x0 = (t % a.tiles_x) * OUTW, y0 = (t / a.tiles_x) * SEGT;
-    const int rows_out = min(SEGT, H - y0);
+    const int64_t base = (int64_t)img * a.js;     // J buffers: padded rows and frames
+    const int JP = a.jp;
+    int sx, y0, rows_out;
+    tile_rows(a, t, sx, y0, rows_out);
+    const int x0 = sx * OUTW;
     const double lam = a.lam[img], lam_prev = a.lam_prev[img];
     const double *j1 = a.j1 + base, *j2 = a.j2 + base, *j3 = a.j3 + base;
-    const WT *wi = reinterpret_cast<const WT *>(a.wi) + base;
+    const WT *wi = reinterpret_cast<const WT *>(a.wi) + (int64_t)img * H * W;
     const int gx = x0 - 2 * R + lane;                 // this lane's column
     const int cm = clampi(gx, 0, W - 1);
     const bool out_lane = lane >= 2 * R && lane < TW - 2 * R && gx < W;
@@ -351,13 +195,13 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
     double m0[P], m1[P], e2[P];
     WT w0[P];
     auto fetch = [&](int u, int r) {
-        const int64_t yrow = (int64_t)clampi(y0 + min(r, rows_out + 2 * R - 1), 0, H - 1) * W;
+        const int64_t yrow = (int64_t)clampi(y0 + min(r, rows_out + 2 * R - 1), 0, H - 1) * JP;
         m0[u] = j1[yrow + cm];
         m1[u] = j2[yrow + cm];
         const int64_t qrow = (int64_t)clampi(y0 + clampi(r - R, -R, rows_out + R - 1), 0, H - 1) * W;
         w0[u] = wi[qrow + cm];
         // J3 is only needed where row r is one of the strip's own output rows
-        const int64_t p = (int64_t)(y0 + clampi(r, 0, rows_out - 1)) * W + cm;
+        const int64_t p = (int64_t)(y0 + clampi(r, 0, rows_out - 1)) * JP + cm;
         e2[u] = j3[p];
     };
 
@@ -422,9 +266,13 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
                     s2 = s2 + a.tp.k[j] * srow2[clampi(gx - R + j, 0, W - 1) + off];
             }
             const int gq = y0 + r - R;                          // image row of this ratio row
-            if (gq >= H) s2 = last_s2;                          // below the bottom edge
+            if (gq >= H) {                                      // below the bottom edge
+                MF_UNIFORM_BRANCH();
+                s2 = last_s2;
+            }
             last_s2 = s2;
             if (gq == 0) {                                      // rows above the top edge
+                MF_UNIFORM_BRANCH();
 #pragma unroll
                 for (int j = 0; j <= 2 * R; ++j) ring2[j] = s2;
             } else {
@@ -437,12 +285,20 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
             for (int j = 1; j <= R; ++j) o = o + a.tp.k[R + j] * (ring2[R + j] + ring2[R - j]);
             // ---- epilogue: output row r - 2R ----
             const int ro = r - 2 * R;
-            const bool ok = ro >= 0 && ro < rows_out && out_lane;
-            const double jn = yo * o;                           // np.multiply(Y, imR, out=J1)
-            const double tn = jn - yo;                          // np.subtract(J1, Y, out=T1)
-            if (ok) a.jnew[base + (int64_t)(y0 + ro) * W + gx] = jn;
-            s_ab = s_ab + (ok ? tn * to : 0.0);                 // cv2.multiply(T1, T2) summed
-            s_bb = s_bb + (ok ? to * to : 0.0);
+            if (ro >= 0 && ro < rows_out) {                     // not a warm-up or drain row
+                MF_UNIFORM_BRANCH();
+                const double jn = yo * o;                       // np.multiply(Y, imR, out=J1)
+                const double tn = jn - yo;                      // np.subtract(J1, Y, out=T1)
+                if (out_lane) a.jnew[base + (int64_t)(y0 + ro) * JP + gx] = jn;
+                // cv2.multiply(T1, T2) summed; lanes that own no output are dropped at the flush
+                s_ab = s_ab + tn * to;
+                s_bb = s_bb + to * to;
+                if (((ro + 1) & (BH - 1)) == 0 || ro == rows_out - 1) {
+                    store_partial(a, img, (y0 + ro) / BH, sx, lane, out_lane ? s_ab : 0.0,
+                                  out_lane ? s_bb : 0.0);
+                    s_ab = s_bb = 0.0;
+                }
+            }
             // the slot's values are dead now: refill it.  The scheduling barrier
             // keeps the loads from being hoisted above the last use of the old
             // values, which would cost a register copy (and a wait for the
@@ -451,69 +307,299 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
             fetch(u, r + P);
         }
     }
-    // strip partials -> last strip of the frame -> next lambda (as lr_stream_kernel)
-    s_ab = wave_sum(s_ab);
-    s_bb = wave_sum(s_bb);
-    unsigned ticket = 0;
-    if (lane == 0) {
-        double *pp = a.partials + ((int64_t)img * a.tiles + t) * 2;
-        atomic_store_f64(pp, s_ab);
-        atomic_store_f64(pp + 1, s_bb);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ticket = atomicAdd(a.counters + img, 1u);
-    }
-    ticket = __shfl(ticket, 0, 64);
-    if (ticket != (unsigned)a.tiles - 1u) return;
-    const double *pp = a.partials + (int64_t)img * a.tiles * 2;
-    double ab = 0.0, bb = 0.0;
-    constexpr int U = 8;
-    for (int i0 = lane; i0 < a.tiles; i0 += 64 * U) {
-        double va[U], vb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 64 * u;
-            va[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i) : 0.0;
-            vb[u] = i < a.tiles ? atomic_load_f64(pp + 2 * i + 1) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + 64 * u < a.tiles) { ab = ab + va[u]; bb = bb + vb[u]; }
-        }
-    }
-    ab = wave_sum(ab);
-    bb = wave_sum(bb);
-    if (lane == 0) {
-        double l = ab / (bb + EPS);                   // deconvolve.py:110
-        l = 1.0 < l ? 1.0 : l;                        // min(l, 1)
-        l = 0.0 > l ? 0.0 : l;                        // max(., 0)
-        if (a.iter + 1 <= 1) l = 0.0;                 // acceleration starts at the third iteration
-        a.lam_next[img] = l;
-        if (a.lam_trace) a.lam_trace[(int64_t)img * a.trace_stride + a.iter + 1] = l;
-        a.counters[img] = 0u;
-    }
 }
 
-template <typename WT>
-__global__ void __launch_bounds__(NT) lr_init_kernel(const WT *wi, double *ja, double *jb, double *t1,
-                                                     int64_t n, int fused)
+// ---- fused iteration, two columns per lane --------------------------------
+// The same pipeline as lr_fused_kernel over 128-column strips: lane L carries
+// columns 2L and 2L + 1 of the strip, so 128 - 4R of 128 columns are outputs
+// (112 at R = 4, against 48 of 64), every global access is 16 bytes per lane,
+// and one row pass reads its 2R + 2 LDS values as R + 1 (+1 for odd R) 16-byte
+// reads for both columns.  The two rings of row sums rotate by renaming when
+// the row loop is unrolled a multiple of 2R + 1 times (U; no register moves),
+// otherwise they shift.  Needs an even image width (a lane's pair is then never
+// split by the right edge) and 16-byte aligned rows; the host falls back to
+// lr_fused_kernel otherwise.  Arithmetic per pixel is unchanged.
+struct alignas(16) D2 { double x, y; };
+struct alignas(4) U2 { uint16_t x, y; };
+template <typename T> struct PairOf;
+template <> struct PairOf<double> { using type = D2; };
+template <> struct PairOf<uint16_t> { using type = U2; };
+
+//
+// MODE = min(iteration, 3).  The J buffers all start as the observed image, so
+// the first iterations read it instead (the same values, converted on the fly;
+// no initialisation pass over the three buffers): iteration 0 takes J1 = J2 =
+// J3 from the observed image, iteration 1 J2 = J3, iteration 2 J3; from
+// iteration 3 on every operand comes from its buffer.
+template <int R, int P, int U, int MODE, typename WT>
+__global__ void __launch_bounds__(64, 2) lr_fused2_kernel(const LrArgs a)
 {
-    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (i < n) {
-        const double v = load_wi(wi, i);
-        ja[i] = v;
-        jb[i] = v;
-        t1[i] = fused ? v : 0.0;     // fused path: the third J buffer
+    using WP = typename PairOf<WT>::type;
+    constexpr int SW = 2 * TW;
+    constexpr int OUTW = SW - 4 * R;
+    constexpr int N = 2 * R + 1;
+    constexpr bool ROT = U % N == 0;               // ring slots renamed instead of shifted
+    static_assert(U % P == 0, "prefetch slots must divide the unroll");
+    constexpr int NRING = R > 0 ? 2 * R : 1;
+    constexpr int PADL = R + (R & 1);              // even: a lane's pair stays 16-byte aligned
+    constexpr int O = PADL - R;                    // first tap of column 2L inside the lane's reads
+    constexpr int NV = (O + 2 * R + 3) / 2;        // 16-byte reads per row pass
+    constexpr int SROW = SW - 2 + 2 * NV;          // >= PADL + SW + R
+    __shared__ __align__(16) double srow1[SROW];
+    __shared__ __align__(16) double srow2[SROW];
+    __shared__ D2 sj1[NRING][TW];
+    __shared__ D2 sj2[NRING][TW];
+    const int t = xcd_tile(a.tiles);
+    if (t < 0) return;
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int64_t base = (int64_t)img * a.js;     // J buffers: padded rows and frames
+    const int JP = a.jp;
+    int sx, y0, rows_out;
+    tile_rows(a, t, sx, y0, rows_out);
+    const int x0 = sx * OUTW;
+    const double lam = a.lam[img], lam_prev = a.lam_prev[img];
+    const double *j1 = a.j1 + base, *j2 = a.j2 + base, *j3 = a.j3 + base;
+    const WT *wi = reinterpret_cast<const WT *>(a.wi) + (int64_t)img * H * W;
+    const int gx = x0 - 2 * R + 2 * lane;             // the first of this lane's two columns (even)
+    const int cp = clampi(gx, 0, W - 2);              // the pair that is loaded for them
+    const bool dup_lo = gx < 0, dup_hi = gx >= W;     // both columns left / right of the image
+    const bool out_lane = lane >= R && lane < TW - R && gx < W;
+    const bool border_x = x0 - 2 * R < 0 || x0 - 2 * R + SW > W;    // wave-uniform
+    for (int i = lane; i < SROW; i += TW)
+        if (i < PADL || i >= PADL + SW) srow1[i] = srow2[i] = 0.0;   // pads: never written again
+    D2 *const row1 = reinterpret_cast<D2 *>(srow1);
+    D2 *const row2 = reinterpret_cast<D2 *>(srow2);
+
+    D2 m0[P], m1[P], e2[P];
+    WP w0[P], wy[P];
+    auto widen = [](const WP &v) { D2 d; d.x = (double)v.x; d.y = (double)v.y; return d; };
+    auto fetch = [&](int u, int r) {
+        const int yr = clampi(y0 + min(r, rows_out + 2 * R - 1), 0, H - 1);
+        const int64_t yrow = (int64_t)yr * JP;
+        if constexpr (MODE >= 1) m0[u] = *reinterpret_cast<const D2 *>(j1 + yrow + cp);
+        if constexpr (MODE >= 2) m1[u] = *reinterpret_cast<const D2 *>(j2 + yrow + cp);
+        const int64_t qrow = (int64_t)clampi(y0 + clampi(r - R, -R, rows_out + R - 1), 0, H - 1) * W;
+        w0[u] = *reinterpret_cast<const WP *>(wi + qrow + cp);
+        // J3 is only needed where row r is one of the strip's own output rows
+        const int pr = y0 + clampi(r, 0, rows_out - 1);
+        if constexpr (MODE >= 3) e2[u] = *reinterpret_cast<const D2 *>(j3 + (int64_t)pr * JP + cp);
+        // the observed image standing in for buffers that still hold it (on the
+        // strip's own rows pr is the Y row, which is where J3 matters)
+        if constexpr (MODE < 2) wy[u] = *reinterpret_cast<const WP *>(wi + (int64_t)yr * W + cp);
+        if constexpr (MODE == 2) wy[u] = *reinterpret_cast<const WP *>(wi + (int64_t)pr * W + cp);
+    };
+
+    double r1x[N], r1y[N], r2x[N], r2y[N];         // row sums of the last 2R + 1 rows, both stages
+#pragma unroll
+    for (int j = 0; j < N; ++j) r1x[j] = r1y[j] = r2x[j] = r2y[j] = 0.0;
+    double ab0 = 0.0, ab1 = 0.0, bb0 = 0.0, bb1 = 0.0, last_x = 0.0, last_y = 0.0;
+
+    // OpenCV RowFilter over the values the lane read: s = k[0] S[0]; s += k[j] S[j]
+    auto row_pass = [&](const double *v, int first) {
+        double s = a.tp.k[0] * v[first];
+#pragma unroll
+        for (int j = 1; j <= 2 * R; ++j) s = s + a.tp.k[j] * v[first + j];
+        return s;
+    };
+
+    const int r_end = rows_out + 2 * R;
+    int slot = 0;
+#pragma unroll
+    for (int u = 0; u < P; ++u) fetch(u, -2 * R + u);
+    for (int rb = -2 * R; rb < r_end; rb += U) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int u = i % P;
+            const int r = rb + i;
+            // ring slot written by this row, and where row sum j (0 = oldest) then lives
+            const int wr = ROT ? i % N : 2 * R;
+            auto at = [&](int j) { return ROT ? (i % N + 1 + j) % N : j; };
+            D2 a1, a2, a3;
+            if constexpr (MODE >= 1) a1 = m0[u]; else a1 = widen(wy[u]);
+            if constexpr (MODE >= 2) a2 = m1[u]; else a2 = widen(wy[u]);
+            if constexpr (MODE >= 3) a3 = e2[u]; else a3 = widen(wy[u]);
+            const WP cw = w0[u];
+            if (border_x) {                     // BORDER_REPLICATE of Y beyond the image's sides
+                if (dup_lo) { a1.y = a1.x; a2.y = a2.x; }
+                if (dup_hi) { a1.x = a1.y; a2.x = a2.y; }
+            }
+            D2 y, told;
+            y.x = make_y(a1.x, a2.x, lam);
+            y.y = make_y(a1.y, a2.y, lam);
+            told.x = a1.x - make_y(a2.x, a3.x, lam_prev);
+            told.y = a1.y - make_y(a2.y, a3.y, lam_prev);
+            // ---- stage 1: reblurred row r - R, ratio ----
+            lds_wave_order();
+            row1[PADL / 2 + lane] = y;
+            D2 yo = y, to = told;
+            if constexpr (R > 0) {
+                yo = sj1[slot][lane];
+                to = sj2[slot][lane];
+                lds_wave_order();
+                sj1[slot][lane] = y;
+                sj2[slot][lane] = told;
+                slot = slot + 1 == NRING ? 0 : slot + 1;
+            }
+            lds_wave_order();
+            double v[2 * NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const D2 tq = row1[lane + q];
+                v[2 * q] = tq.x;
+                v[2 * q + 1] = tq.y;
+            }
+            const double s1x = row_pass(v, O), s1y = row_pass(v, O + 1);
+            if constexpr (!ROT) {
+#pragma unroll
+                for (int j = 0; j < 2 * R; ++j) { r1x[j] = r1x[j + 1]; r1y[j] = r1y[j + 1]; }
+            }
+            r1x[wr] = s1x;
+            r1y[wr] = s1y;
+            double bx = a.tp.k[R] * r1x[at(R)], by = a.tp.k[R] * r1y[at(R)];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) {
+                bx = bx + a.tp.k[R + j] * (r1x[at(R + j)] + r1x[at(R - j)]);
+                by = by + a.tp.k[R + j] * (r1y[at(R + j)] + r1y[at(R - j)]);
+            }
+            bx = bx < EPS ? EPS : bx;                           // np.clip(reblurred, eps, None)
+            by = by < EPS ? EPS : by;
+            D2 ratio;
+            ratio.x = (double)cw.x / bx + EPS;                  // cv2.divide; imR += eps
+            ratio.y = (double)cw.y / by + EPS;
+            // ---- stage 2: blurred ratio row r - 2R ----
+            row2[PADL / 2 + lane] = ratio;
+            lds_wave_order();
+            double s2x, s2y;
+            if (!border_x) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const D2 tq = row2[lane + q];
+                    v[2 * q] = tq.x;
+                    v[2 * q + 1] = tq.y;
+                }
+                s2x = row_pass(v, O);
+                s2y = row_pass(v, O + 1);
+            } else {
+                // tap j of column c sits at column c - R + j: replicate the image's edge columns
+                const int off = PADL - (x0 - 2 * R);            // column -> srow2 index
+                s2x = a.tp.k[0] * srow2[clampi(gx - R, 0, W - 1) + off];
+                s2y = a.tp.k[0] * srow2[clampi(gx + 1 - R, 0, W - 1) + off];
+#pragma unroll
+                for (int j = 1; j <= 2 * R; ++j) {
+                    s2x = s2x + a.tp.k[j] * srow2[clampi(gx - R + j, 0, W - 1) + off];
+                    s2y = s2y + a.tp.k[j] * srow2[clampi(gx + 1 - R + j, 0, W - 1) + off];
+                }
+            }
+            const int gq = y0 + r - R;                          // image row of this ratio row
+            if (gq >= H) {                                      // below the bottom edge
+                MF_UNIFORM_BRANCH();
+                s2x = last_x;
+                s2y = last_y;
+            }
+            last_x = s2x;
+            last_y = s2y;
+            if (gq == 0) {                                      // rows above the top edge
+                MF_UNIFORM_BRANCH();
+#pragma unroll
+                for (int j = 0; j < N; ++j) { r2x[j] = s2x; r2y[j] = s2y; }
+            } else {
+                if constexpr (!ROT) {
+#pragma unroll
+                    for (int j = 0; j < 2 * R; ++j) { r2x[j] = r2x[j + 1]; r2y[j] = r2y[j + 1]; }
+                }
+                r2x[wr] = s2x;
+                r2y[wr] = s2y;
+            }
+            double ox = a.tp.k[R] * r2x[at(R)], oy = a.tp.k[R] * r2y[at(R)];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) {
+                ox = ox + a.tp.k[R + j] * (r2x[at(R + j)] + r2x[at(R - j)]);
+                oy = oy + a.tp.k[R + j] * (r2y[at(R + j)] + r2y[at(R - j)]);
+            }
+            // ---- epilogue: output row r - 2R ----
+            const int ro = r - 2 * R;
+            if (ro >= 0 && ro < rows_out) {                     // not a warm-up or drain row
+                MF_UNIFORM_BRANCH();
+                D2 jn;
+                jn.x = yo.x * ox;                               // np.multiply(Y, imR, out=J1)
+                jn.y = yo.y * oy;
+                const double tnx = jn.x - yo.x, tny = jn.y - yo.y;      // np.subtract(J1, Y, out=T1)
+                if (out_lane) *reinterpret_cast<D2 *>(a.jnew + base + (int64_t)(y0 + ro) * JP + gx) = jn;
+                // cv2.multiply(T1, T2) summed; lanes that own no output are dropped at the flush
+                ab0 = ab0 + tnx * to.x;
+                ab1 = ab1 + tny * to.y;
+                bb0 = bb0 + to.x * to.x;
+                bb1 = bb1 + to.y * to.y;
+                if (((ro + 1) & (BH - 1)) == 0 || ro == rows_out - 1) {
+                    store_partial(a, img, (y0 + ro) / BH, sx, lane, out_lane ? ab0 + ab1 : 0.0,
+                                  out_lane ? bb0 + bb1 : 0.0);
+                    ab0 = ab1 = bb0 = bb1 = 0.0;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // as in lr_fused_kernel
+            fetch(u, r + P);
+        }
     }
 }
 
-__global__ void lr_reset_kernel(double *lam, double *lam_trace, int64_t trace_stride,
-                                unsigned *counters, int n)
+// observed image [n][H][W] -> the three J buffers [n][js] with row pitch jp
+template <typename WT>
+__global__ void __launch_bounds__(NT) lr_init_kernel(const WT *wi, double *ja, double *jb, double *jc,
+                                                     int W, int64_t hw, int jp, int64_t js)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;      // pixel of frame blockIdx.y
+    if (i < hw) {
+        const double v = load_wi(wi, (int64_t)blockIdx.y * hw + i);
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const int64_t o = (int64_t)blockIdx.y * js + (int64_t)y * jp + x;
+        ja[o] = v;
+        jb[o] = v;
+        jc[o] = v;
+    }
+}
+
+__global__ void lr_reset_kernel(double *lam, double *lam_trace, int64_t trace_stride, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         lam[i] = lam[n + i] = lam[2 * n + i] = 0.0;
-        counters[i] = 0u;
         if (lam_trace) lam_trace[(int64_t)i * trace_stride] = 0.0;
+    }
+}
+
+// lambda of the next iteration from the strips' partial sums (deconvolve.py:
+// 107-110): one block per frame; thread i adds partials i, i + 256, ... in
+// order, the four waves add their lanes in a fixed tree, then wave 0 .. 3 in
+// order.  No float atomics: identical from run to run, for every batch size
+// and every cut of the frame into segments.
+__global__ void __launch_bounds__(NT) lr_lambda_kernel(const double *partials, int count, int iter,
+                                                       double *lam_next, double *lam_trace,
+                                                       int64_t trace_stride)
+{
+    __shared__ double sw[2][NT / 64];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const double *pp = partials + (int64_t)img * count * 2;
+    double ab = 0.0, bb = 0.0;
+    for (int i = tid; i < count; i += NT) {
+        ab = ab + pp[2 * i];
+        bb = bb + pp[2 * i + 1];
+    }
+    ab = wave_sum(ab);
+    bb = wave_sum(bb);
+    if ((tid & 63) == 0) { sw[0][tid >> 6] = ab; sw[1][tid >> 6] = bb; }
+    __syncthreads();
+    if (tid == 0) {
+        ab = sw[0][0]; bb = sw[1][0];
+        for (int w = 1; w < NT / 64; ++w) { ab = ab + sw[0][w]; bb = bb + sw[1][w]; }
+        double l = ab / (bb + EPS);                   // deconvolve.py:110
+        l = 1.0 < l ? 1.0 : l;                        // min(l, 1)
+        l = 0.0 > l ? 0.0 : l;                        // max(., 0)
+        // the reference only starts accelerating at its third iteration
+        if (iter + 1 <= 1) l = 0.0;
+        lam_next[img] = l;
+        if (lam_trace) lam_trace[(int64_t)img * trace_stride + iter + 1] = l;
     }
 }
 
@@ -530,13 +616,13 @@ constexpr int HIST_BLOCKS = 64;      // blocks per image
 
 // J1 -> output (+ histogram over np.arange(0, 65535): 65534 bins, the last one
 // closed on the right, 65535 outside; preprocess.py:114-129)
-__global__ void __launch_bounds__(NT) lr_finalize_kernel(const double *j, void *out, int out_f64,
-                                                         int64_t hw, unsigned long long *hist,
-                                                         int hist_group, int img0)
+__global__ void __launch_bounds__(NT) lr_finalize_kernel(const double *j, int W, int jp, int64_t js,
+                                                         void *out, int out_f64, int64_t hw,
+                                                         unsigned long long *hist, int hist_group, int img0)
 {
     __shared__ unsigned low[HIST_LOW];
     const int img = blockIdx.y;
-    const double *src = j + (int64_t)img * hw;
+    const double *src = j + (int64_t)img * js;
     if (hist)
         for (int i = threadIdx.x; i < HIST_LOW; i += NT) low[i] = 0u;
     __syncthreads();
@@ -545,7 +631,8 @@ __global__ void __launch_bounds__(NT) lr_finalize_kernel(const double *j, void *
     const int64_t lo = (int64_t)blockIdx.x * per, hi = min(hw, lo + per);
     unsigned zeros = 0;      // most deconvolved pixels are 0: one LDS add per thread, not per pixel
     for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
-        const double v = src[i];
+        const int y = (int)(i / W);
+        const double v = src[(int64_t)y * jp + (i - (int64_t)y * W)];
         if (out_f64) {
             reinterpret_cast<double *>(out)[(int64_t)img * hw + i] = v;
         } else {
@@ -724,27 +811,50 @@ int fill_taps(int ksize, double sigma, Taps &tp)
 inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
 struct Workspace {
-    double *ja, *jb, *t1, *ratio, *partials, *lam;
-    unsigned *counters;
+    double *ja, *jb, *jc, *partials, *lam;
     uint16_t *wi16;
+    int jp;          // row pitch of ja / jb / jc, in doubles
+    int64_t js;      // their frame stride, in doubles
     size_t total;
 };
+
+#ifndef MF_LR_PADX
+#define MF_LR_PADX 0
+#endif
+#ifndef MF_LR_PADF
+#define MF_LR_PADF 0
+#endif
+
+// Row and frame padding of the J buffers, in doubles (both even, so that pairs
+// of columns stay 16-byte aligned).
+void j_padding(int &padx, int64_t &padf)
+{
+    padx = MF_LR_PADX;
+    padf = MF_LR_PADF;
+#ifdef MF_LR_TUNE
+    if (std::getenv("MF_LR_PADX")) padx = std::atoi(std::getenv("MF_LR_PADX")) & ~1;
+    if (std::getenv("MF_LR_PADF")) padf = std::atoll(std::getenv("MF_LR_PADF")) & ~1ll;
+#endif
+}
 
 void layout_workspace(int batch, int H, int W, unsigned char *base, Workspace &ws)
 {
     const size_t hw = (size_t)H * W;
-    // strips of the fused kernel at its narrowest (R = 6: 40 output columns)
-    const size_t tiles = (size_t)((W + 39) / 40) * ((H + SEG - 1) / SEG);
+    // strips of the one-column kernel at its narrowest (R = 6: 40 output columns)
+    const size_t cells = (size_t)((W + 39) / 40) * ((H + BH - 1) / BH);
     size_t off = 0;
     auto take = [&](size_t bytes) { unsigned char *p = base + off; off += align256(bytes); return p; };
-    ws.ja = reinterpret_cast<double *>(take(batch * hw * 8));
-    ws.jb = reinterpret_cast<double *>(take(batch * hw * 8));
-    ws.t1 = reinterpret_cast<double *>(take(batch * hw * 8));
-    ws.ratio = reinterpret_cast<double *>(take(batch * hw * 8));
+    int padx;
+    int64_t padf;
+    j_padding(padx, padf);
+    ws.jp = W + padx;
+    ws.js = (int64_t)H * ws.jp + padf;
+    ws.ja = reinterpret_cast<double *>(take(batch * ws.js * 8));
+    ws.jb = reinterpret_cast<double *>(take(batch * ws.js * 8));
+    ws.jc = reinterpret_cast<double *>(take(batch * ws.js * 8));
     ws.wi16 = reinterpret_cast<uint16_t *>(take(batch * hw * 2));
-    ws.partials = reinterpret_cast<double *>(take(batch * tiles * 16));
+    ws.partials = reinterpret_cast<double *>(take(batch * cells * 16));
     ws.lam = reinterpret_cast<double *>(take((size_t)batch * 3 * 8));
-    ws.counters = reinterpret_cast<unsigned *>(take((size_t)batch * 4));
     ws.total = off;
 }
 
@@ -752,47 +862,98 @@ void layout_workspace(int batch, int H, int W, unsigned char *base, Workspace &w
 #define MF_LR_PREFETCH 4
 #endif
 
-template <int R, int P, typename WT>
-int launch_iteration_p(const LrArgs &a, int n, hipStream_t s)
+// Wave slots of the chip for a single-wave kernel: resident workgroups per CU
+// (registers, LDS) x CUs of the current device.
+template <typename K>
+int wave_slots(K kernel)
 {
-    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
-    hipLaunchKernelGGL((lr_stream_kernel<R, SEG, P, WT, false>), grid, dim3(64), 0, s, a);
-    hipLaunchKernelGGL((lr_stream_kernel<R, SEG, P, WT, true>), grid, dim3(64), 0, s, a);
-    MF_HIP_CHECK(hipGetLastError());
-    return MF_OK;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1)
+        per_cu = 8;
+    if (hipGetDevice(&dev) != hipSuccess
+        || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    return per_cu * cus;
 }
 
-template <int R, typename WT>
-int launch_iteration(const LrArgs &a, int n, hipStream_t s)
+// Segments per strip for one launch of `strips` strip columns (tiles_x x
+// frames).  Every segment streams its rows plus `halo` warm-up rows, and the
+// launch runs in rounds of `slots` concurrent waves; a partly filled last round
+// takes about as long as a full one (a wave alone is bound by its own latency:
+// measured 1.39 us per row at half occupancy against 1.64 at full), so with one
+// fixed height (r01: 128 rows) up to a fifth of a launch was spent there.
+// Cost: mean rows per segment x rounds, rounded up.  Measured at 28 frames of
+// 2048 x 2048 (19 strips, 2048 slots), ms per frame: 7 segments 0.665, 11
+// 0.651, 15 0.652, 16 0.659, 19 0.697; the rule picks 11.
+int choose_segments(int64_t strips, int nblk, int halo, int slots)
 {
-#ifdef MF_LR_TUNE      // development build: prefetch depth from the environment
-    if (R == 4) {
-        static const int p = std::getenv("MF_LR_P") ? std::atoi(std::getenv("MF_LR_P")) : MF_LR_PREFETCH;
-        switch (p) {
-        case 1: return launch_iteration_p<R, 1, WT>(a, n, s);
-        case 2: return launch_iteration_p<R, 2, WT>(a, n, s);
-        case 3: return launch_iteration_p<R, 3, WT>(a, n, s);
-        case 6: return launch_iteration_p<R, 6, WT>(a, n, s);
-        case 8: return launch_iteration_p<R, 8, WT>(a, n, s);
-        }
+#ifdef MF_LR_TUNE
+    if (std::getenv("MF_LR_NSEG")) {
+        const int v = std::atoi(std::getenv("MF_LR_NSEG"));
+        return v < 1 ? 1 : v > nblk ? nblk : v;
     }
 #endif
-    return launch_iteration_p<R, MF_LR_PREFETCH, WT>(a, n, s);
+    const int most = nblk / SEG_MIN_BLOCKS > 1 ? nblk / SEG_MIN_BLOCKS : 1;
+    int best = 1;
+    double best_cost = 0.0;
+    for (int n = 1; n <= most; ++n) {
+        const double rows = (double)nblk * BH / n + halo;
+        const int64_t waves = strips * n;
+        const double cost = rows * (double)((waves + slots - 1) / slots);
+        if (n == 1 || cost < best_cost) { best = n; best_cost = cost; }
+    }
+#ifdef MF_LR_TUNE
+    if (std::getenv("MF_LR_VERBOSE"))
+        fprintf(stderr, "choose_segments: strips %lld nblk %d halo %d slots %d -> %d\n", (long long)strips,
+                nblk, halo, slots, best);
+#endif
+    return best;
 }
 
 template <int R, typename WT>
-int launch_fused(const LrArgs &a, int n, hipStream_t s)
+int launch_fused(LrArgs a, int n, hipStream_t s)
 {
+    auto kernel = lr_fused_kernel<R, MF_LR_PREFETCH, WT>;
+    static const int slots = wave_slots(kernel);
+    a.nseg = choose_segments((int64_t)a.tiles_x * n, a.nblk, 4 * R, slots);
+    a.tiles = a.tiles_x * a.nseg;
     const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
-    hipLaunchKernelGGL((lr_fused_kernel<R, SEG, MF_LR_PREFETCH, WT>), grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(64), 0, s, a);
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
 }
 
-template <typename WT>
-int dispatch_fused(int R, const LrArgs &a, int n, hipStream_t s)
+// prefetch depth P and unroll U of the two-column kernel per radius: U is a
+// multiple of 2R + 1 where that keeps the code small (rings rotate by renaming)
+template <int R> struct Fused2Shape {
+    static constexpr int N = 2 * R + 1;
+    static constexpr int U = N == 3 || N == 5 || N == 9 ? N : N < 9 ? 4 : 3;
+    static constexpr int P = N == 9 ? 3 : U;
+};
+
+template <int R, typename WT>
+int launch_fused2(LrArgs a, int n, int mode, hipStream_t s)
 {
-    switch (R) {
+    constexpr int P = Fused2Shape<R>::P, U = Fused2Shape<R>::U;
+    static const int slots = wave_slots(lr_fused2_kernel<R, P, U, 3, WT>);
+    a.nseg = choose_segments((int64_t)a.tiles_x * n, a.nblk, 4 * R, slots);
+    a.tiles = a.tiles_x * a.nseg;
+    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 0, WT>), grid, dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 1, WT>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 2, WT>), grid, dim3(64), 0, s, a); break;
+    default: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 3, WT>), grid, dim3(64), 0, s, a); break;
+    }
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
+// mode: the iteration number (two-column kernel only; see lr_fused2_kernel)
+template <typename WT>
+int dispatch_fused(int R, bool pairs, const LrArgs &a, int n, int mode, hipStream_t s)
+{
+    switch (pairs ? R + 16 : R) {
     case 0: return launch_fused<0, WT>(a, n, s);
     case 1: return launch_fused<1, WT>(a, n, s);
     case 2: return launch_fused<2, WT>(a, n, s);
@@ -800,37 +961,26 @@ int dispatch_fused(int R, const LrArgs &a, int n, hipStream_t s)
     case 4: return launch_fused<4, WT>(a, n, s);
     case 5: return launch_fused<5, WT>(a, n, s);
     case 6: return launch_fused<6, WT>(a, n, s);
+    case 16: return launch_fused2<0, WT>(a, n, mode, s);
+    case 17: return launch_fused2<1, WT>(a, n, mode, s);
+    case 18: return launch_fused2<2, WT>(a, n, mode, s);
+    case 19: return launch_fused2<3, WT>(a, n, mode, s);
+    case 20: return launch_fused2<4, WT>(a, n, mode, s);
+    case 21: return launch_fused2<5, WT>(a, n, mode, s);
+    case 22: return launch_fused2<6, WT>(a, n, mode, s);
     }
     return mf::fail(MF_EUNSUPPORTED, "deconvolution filter radius %d > 6", R);
 }
 
-// The two-launch iteration (lr_stream_kernel reblur + update through a ratio
-// buffer) instead of the fused one is kept for comparison: development builds
-// (-DMF_LR_TUNE) read MF_LR_SPLIT=1 from the environment once; the release
-// build has no environment knobs.
-bool use_fused()
+// development builds can switch the two-column kernel off (MF_LR_PAIRS=0)
+bool use_pairs()
 {
 #ifdef MF_LR_TUNE
-    static const bool fused = !(std::getenv("MF_LR_SPLIT") && std::atoi(std::getenv("MF_LR_SPLIT")));
-    return fused;
+    static const bool on = !(std::getenv("MF_LR_PAIRS") && !std::atoi(std::getenv("MF_LR_PAIRS")));
+    return on;
 #else
     return true;
 #endif
-}
-
-template <typename WT>
-int dispatch_iteration(int R, const LrArgs &a, int n, hipStream_t s)
-{
-    switch (R) {
-    case 0: return launch_iteration<0, WT>(a, n, s);
-    case 1: return launch_iteration<1, WT>(a, n, s);
-    case 2: return launch_iteration<2, WT>(a, n, s);
-    case 3: return launch_iteration<3, WT>(a, n, s);
-    case 4: return launch_iteration<4, WT>(a, n, s);
-    case 5: return launch_iteration<5, WT>(a, n, s);
-    case 6: return launch_iteration<6, WT>(a, n, s);
-    }
-    return mf::fail(MF_EUNSUPPORTED, "deconvolution filter radius %d > 6", R);
 }
 
 int check_shape(int n, int H, int W, int batch)
@@ -881,47 +1031,46 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
                  Workspace &ws, hipStream_t s)
 {
     const int64_t hw = (int64_t)H * W;
-    const int64_t total = hw * nb;
-    const bool fused = use_fused();
-    hipLaunchKernelGGL(lr_init_kernel<WT>, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, wi,
-                       ws.ja, ws.jb, ws.t1, total, (int)fused);
     double *trace = lam_trace ? lam_trace + (int64_t)i0 * iterations : nullptr;
     hipLaunchKernelGGL(lr_reset_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, ws.lam,
-                       iterations > 0 ? trace : nullptr, (int64_t)iterations, ws.counters, nb);
+                       iterations > 0 ? trace : nullptr, (int64_t)iterations, nb);
     LrArgs a;
     std::memset(&a, 0, sizeof(a));
     a.wi = wi;
-    a.ratio = ws.ratio;
-    a.t1 = ws.t1;
     a.partials = ws.partials;
-    a.counters = ws.counters;
     a.H = H; a.W = W;
-    const int strip_w = fused ? TW - 4 * R : TW;
+    a.jp = ws.jp; a.js = ws.js;
+    // two columns per lane when no pair of columns can straddle the right edge
+    // and every row starts 16-byte aligned (4 bytes for the uint16 image)
+    const bool pairs = use_pairs() && W >= 2 && !(W & 1)
+        && !(reinterpret_cast<uintptr_t>(wi) & (2 * sizeof(WT) - 1))
+        && !(reinterpret_cast<uintptr_t>(ws.ja) & 15) && !(ws.jp & 1) && !(ws.js & 1);
+    // the two-column kernel reads the observed image in place of buffers that
+    // would only hold a copy of it; the one-column kernel starts from copies
+    if (!pairs || iterations == 0)
+        hipLaunchKernelGGL(lr_init_kernel<WT>, dim3((unsigned)((hw + NT - 1) / NT), (unsigned)nb), dim3(NT),
+                           0, s, wi, ws.ja, ws.jb, ws.jc, W, hw, ws.jp, ws.js);
+    const int strip_w = (pairs ? 2 * TW : TW) - 4 * R;
     a.tiles_x = (W + strip_w - 1) / strip_w;
-    a.tiles = a.tiles_x * ((H + SEG - 1) / SEG);
+    a.nblk = (H + BH - 1) / BH;
     a.tp = tp;
-    a.trace_stride = iterations;
-    double *j1 = ws.ja, *j2 = ws.jb, *j3 = ws.t1;
+    double *j1 = ws.ja, *j2 = ws.jb, *j3 = ws.jc;
     for (int it = 0; it < iterations; ++it) {
         a.j1 = j1; a.j2 = j2; a.j3 = j3;
-        a.jnew = fused ? j3 : j2;
+        a.jnew = j3;
         a.lam = ws.lam + (size_t)(it % 3) * nb;
-        a.lam_next = ws.lam + (size_t)((it + 1) % 3) * nb;
         a.lam_prev = ws.lam + (size_t)((it + 2) % 3) * nb;
-        a.lam_trace = it + 1 < iterations ? trace : nullptr;
-        a.iter = it;
-        int rc = fused ? dispatch_fused<WT>(R, a, nb, s) : dispatch_iteration<WT>(R, a, nb, s);
+        int rc = dispatch_fused<WT>(R, pairs, a, nb, it, s);
         if (rc) return rc;
-        if (fused) {         // (J1, J2, J3) <- (J1', J1, J2)
-            double *tmp = j3; j3 = j2; j2 = j1; j1 = tmp;
-        } else {
-            double *tmp = j1; j1 = j2; j2 = tmp;
-        }
+        hipLaunchKernelGGL(lr_lambda_kernel, dim3((unsigned)nb), dim3(NT), 0, s, ws.partials,
+                           a.nblk * a.tiles_x, it, ws.lam + (size_t)((it + 1) % 3) * nb,
+                           it + 1 < iterations ? trace : nullptr, (int64_t)iterations);
+        double *tmp = j3; j3 = j2; j2 = j1; j1 = tmp;     // (J1, J2, J3) <- (J1', J1, J2)
     }
     void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
                         : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
-    hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, j1, dst,
-                       out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
+    hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, j1, W, ws.jp,
+                       ws.js, dst, out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
 }
@@ -953,8 +1102,8 @@ int run_guo_batch(const WT *img, int nb, int i0, int H, int W, int K, const doub
     }
     void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
                         : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
-    hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, ws.ja, dst,
-                       out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
+    hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, ws.ja, W, W, hw,
+                       dst, out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
 }

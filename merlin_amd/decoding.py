@@ -79,6 +79,21 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _bucketed(shape, dtype, device, quantum=4 << 20):
+    """Uninitialised device tensor of ``shape`` carved from an allocation whose
+    size is rounded up to ``quantum`` bytes: table sizes differ a little from
+    FOV to FOV, and exact sizes would make torch's caching allocator grow (a
+    hipMalloc, 5-8 ms) whenever a FOV is slightly larger than every block it
+    holds.  The view keeps the allocation alive."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty(0, dtype=dtype).element_size()
+    cap = max(quantum, -(-nbytes // quantum) * quantum)
+    raw = torch.empty(cap, dtype=torch.uint8, device=device)
+    return raw[:nbytes].view(dtype).view(tuple(shape))
+
+
 def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -453,19 +468,16 @@ class PixelBasedDecoder(object):
         n_pix, n_reg = int(hcounts[0]), int(hcounts[1])
         with torch.cuda.device(dev):
             sp = _stream_ptr(dev)
-            rec = torch.empty((n_reg, _lib.MF_REC_COLS), dtype=torch.float64,
-                              device=dev)
-            inten = torch.empty((n_reg, B), dtype=torch.float32, device=dev)
+            rec = _bucketed((n_reg, _lib.MF_REC_COLS), torch.float64, dev)
+            inten = _bucketed((n_reg, B), torch.float32, dev)
             mean_tm = min_tm = None
             if withRefactorStats:
-                mean_tm = torch.empty((n_reg, B), dtype=torch.float32,
-                                      device=dev)
-                min_tm = torch.empty((n_reg, B), dtype=torch.float32,
-                                     device=dev)
+                mean_tm = _bucketed((n_reg, B), torch.float32, dev)
+                min_tm = _bucketed((n_reg, B), torch.float32, dev)
             if n_reg > 0:
                 ws_bytes = _lib.check(L.mf_region_workspace_bytes(
                     Z, H, W, n_pix, n_reg))
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                ws = _bucketed((ws_bytes,), torch.uint8, dev, 16 << 20)
                 dist = vol.distances if vol.distances is not None \
                     else vol.magnitudes
                 ddt = _lib.MF_DTYPE_F64 if dist.dtype == torch.float64 \
@@ -609,13 +621,14 @@ class PixelBasedDecoder(object):
                 run.wait_stream(cur)
             with torch.cuda.stream(run):
                 ws_bytes = _lib.check(L.mf_region_frame_workspace_bytes(n))
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                ws = _bucketed((ws_bytes,), torch.uint8, dev)
                 if _FRAME_VIA_COPY:
                     # rows into device buffers, then the copy engine moves
                     # them: no workgroup sits on PCIe beside the next decode
-                    outs = [None if h is None else torch.empty_like(h, device=dev)
+                    outs = [None if h is None
+                            else _bucketed(h.shape, h.dtype, dev)
                             for h in hosts]
-                    o32 = torch.empty_like(h32, device=dev)
+                    o32 = _bucketed(h32.shape, h32.dtype, dev)
                     ocount = torch.empty_like(hcount, device=dev)
                 else:
                     outs, o32, ocount = hosts, h32, hcount

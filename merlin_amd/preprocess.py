@@ -20,7 +20,16 @@ from merlin_amd import _lib
 
 HIST_BINS = _lib.MF_HIST_BINS
 # working set per pixel and image inside mf_deconvolve_lucyrichardson
-_BYTES_PER_PIXEL = 34
+_BYTES_PER_PIXEL = 26
+
+
+def algorithmic_bytes_per_pixel(iterations: int = 20) -> int:
+    """HBM bytes per pixel the preprocess stage has to move:
+    high-pass 4, Lucy-Richardson iteration 0 reads the observed image and
+    writes J (10), iteration 1 also reads J1 (18), iteration 2 J1 and J2
+    (26), every later one J1, J2, J3 and the observed image (34), hand-over to
+    uint16 10."""
+    return 4 + sum(min(10 + 8 * i, 34) for i in range(iterations)) + 10
 _WORKSPACE_TARGET = 4 << 30
 
 
