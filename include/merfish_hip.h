@@ -282,6 +282,28 @@ int mf_deconvolve_lucyrichardson(const void *image, int image_dtype,
                                  void *workspace, int64_t workspace_bytes,
                                  void *stream);
 
+/* deconvolve_lucyrichardson with an EVEN windowSize (merlin/util/deconvolve.py:
+ * 102-104, 118-119, 126-128): both blurs of an iteration are
+ * scipy.ndimage.convolve(x, matlab_gauss2D((w, w), sigma), mode='constant') --
+ * a non-separable kernel, zeros outside the image, ndimage's own tap order and
+ * origin -- and the blurred ratio is zeroed where it exceeds 2^16.
+ *   h_weights  HOST f64 [window_size, window_size]: the kernel as
+ *              matlab_gauss2D (merlin/util/matlab.py:11-24) returns it,
+ *              unflipped; window_size <= 16 (odd sizes are accepted and follow
+ *              ndimage's rules too, but the reference sends odd windows to
+ *              cv2.GaussianBlur = mf_deconvolve_lucyrichardson)
+ * Other arguments as mf_deconvolve_lucyrichardson (same workspace). */
+int mf_deconvolve_lucyrichardson_kernel2d(const void *image, int image_dtype,
+                                          int n_images, int H, int W,
+                                          int window_size,
+                                          const double *h_weights,
+                                          int iterations, void *out,
+                                          int out_dtype, int64_t *histogram,
+                                          int hist_group, double *lambdas,
+                                          int batch, void *workspace,
+                                          int64_t workspace_bytes,
+                                          void *stream);
+
 /* deconvolve_lucyrichardson_guo (merlin/util/deconvolve.py:136-174), what
  * DeconvolutionPreprocessGuo runs (analysis/preprocess.py:143-164): per
  * iteration two cv2.filter2D correlations (BORDER_REPLICATE) with the forward

@@ -35,7 +35,8 @@ EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
            'mf_region_frame_static', 'mf_region_frame_typed',
            'mf_high_pass_filter', 'mf_preprocess_workspace_bytes',
            'mf_deconvolve_lucyrichardson', 'mf_preprocess_images',
-           'mf_deconvolve_lucyrichardson_guo')
+           'mf_deconvolve_lucyrichardson_guo',
+           'mf_deconvolve_lucyrichardson_kernel2d')
 
 _lib = None
 
@@ -104,6 +105,10 @@ def lib():
     L.mf_deconvolve_lucyrichardson_guo.argtypes = [
         vp, i32, i32, i32, i32, i32, c.POINTER(c.c_double),
         c.POINTER(c.c_double), i32, vp, i32, vp, i32, i32, vp, i64, vp]
+    L.mf_deconvolve_lucyrichardson_kernel2d.restype = i32
+    L.mf_deconvolve_lucyrichardson_kernel2d.argtypes = [
+        vp, i32, i32, i32, i32, i32, c.POINTER(c.c_double), i32, vp, i32, vp,
+        i32, vp, i32, vp, i64, vp]
     L.mf_preprocess_images.restype = i32
     L.mf_preprocess_images.argtypes = [
         vp, i32, i32, i32, f64, i32, f64, i32, vp, vp, i32, i32, vp, i64, vp]

@@ -708,6 +708,116 @@ __global__ void __launch_bounds__(NT) high_pass_kernel(const HpArgs a)
     }
 }
 
+// ---- even windows: the reference's scipy.ndimage.convolve branch -------------
+// deconvolve.py:102-104, 118-119, 126-128: with an even windowSize both blurs of
+// an iteration are ndimage.convolve(x, matlab_gauss2D, mode='constant') -- a
+// non-separable K x K kernel, zeros outside the image -- and the blurred ratio
+// is zeroed where it exceeds 2^16.  ndimage flips the kernel, moves the origin
+// of an even axis by one, drops taps with |w| <= DBL_EPSILON and adds the rest
+// in row-major order into a float64 that starts at 0 (ni_filters.c
+// NI_Correlate): the host hands over the flipped, thresholded kernel and its
+// centre, the kernel below adds in that order.  A rare configuration (the
+// reference's own default is odd): one LDS-tiled launch per iteration that
+// carries both blurs (the ratio tile is rebuilt with its halo instead of being
+// stored), the same three-buffer rotation, partial sums per tile.
+constexpr int CONV_MAXK = 16;
+constexpr int CONV_TH = 16;
+
+struct ConvArgs {
+    const void *wi;
+    const double *j1, *j2, *j3;
+    double *jnew;
+    const double *lam, *lam_prev;
+    double *partials;        // [n][tiles][2]
+    int H, W, jp;
+    int64_t js;
+    int tiles_x, tiles;
+    int K, c;                // kernel size; index of the centre tap in the flipped kernel
+    double k[CONV_MAXK * CONV_MAXK];
+};
+
+template <typename WT>
+__global__ void __launch_bounds__(NT) lr_conv2d_kernel(const ConvArgs a)
+{
+    // Y tile: the outputs' taps' taps; ratio tile: the outputs' taps
+    __shared__ double ytile[(CONV_TH + 2 * CONV_MAXK - 2) * (TW + 2 * CONV_MAXK - 2)];
+    __shared__ double rtile[(CONV_TH + CONV_MAXK - 1) * (TW + CONV_MAXK - 1)];
+    __shared__ double sw[2][NT / 64];
+    const int t = xcd_tile(a.tiles);
+    if (t < 0) return;
+    const int img = blockIdx.y;
+    const int K = a.K, lo = a.c, H = a.H, W = a.W, JP = a.jp;
+    const int YW = TW + 2 * K - 2, YH = CONV_TH + 2 * K - 2;
+    const int RW = TW + K - 1, RH = CONV_TH + K - 1;
+    const int64_t jbase = (int64_t)img * a.js;
+    const double *j1 = a.j1 + jbase, *j2 = a.j2 + jbase, *j3 = a.j3 + jbase;
+    const WT *wi = reinterpret_cast<const WT *>(a.wi) + (int64_t)img * H * W;
+    const double lam = a.lam[img], lam_prev = a.lam_prev[img];
+    const int x0 = (t % a.tiles_x) * TW, y0 = (t / a.tiles_x) * CONV_TH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < YW * YH; e += NT) {
+        const int r = e / YW, c = e - r * YW;
+        const int gy = y0 - 2 * lo + r, gx = x0 - 2 * lo + c;
+        double v = 0.0;                                   // mode='constant', cval 0
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const int64_t p = (int64_t)gy * JP + gx;
+            v = make_y(j1[p], j2[p], lam);
+        }
+        ytile[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < RW * RH; e += NT) {
+        const int r = e / RW, c = e - r * RW;
+        const int gy = y0 - lo + r, gx = x0 - lo + c;
+        double v = 0.0;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            double s = 0.0;
+            for (int ky = 0; ky < K; ++ky)
+                for (int kx = 0; kx < K; ++kx) {
+                    const double kv = a.k[ky * K + kx];
+                    if (kv != 0.0) s = s + ytile[(r + ky) * YW + c + kx] * kv;
+                }
+            s = s < EPS ? EPS : s;                         // np.clip(reblurred, eps, None)
+            v = load_wi(wi, (int64_t)gy * W + gx) / s + EPS;      // cv2.divide; imR += eps
+        }
+        rtile[e] = v;
+    }
+    __syncthreads();
+    const int gx = x0 + lane;
+    double s_ab = 0.0, s_bb = 0.0;
+    for (int o = 0; o < CONV_TH / 4; ++o) {
+        const int ly = wave * (CONV_TH / 4) + o, gy = y0 + ly;
+        if (gy >= H || gx >= W) continue;
+        double s = 0.0;
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) {
+                const double kv = a.k[ky * K + kx];
+                if (kv != 0.0) s = s + rtile[(ly + ky) * RW + lane + kx] * kv;
+            }
+        if (s > 65536.0) s = 0.0;                          // imR[imR > 2 ** 16] = 0
+        const int64_t p = (int64_t)gy * JP + gx;
+        const double a1 = j1[p], a2 = j2[p];
+        const double y = make_y(a1, a2, lam);
+        const double told = a1 - make_y(a2, j3[p], lam_prev);     // last iteration's T1
+        const double jn = y * s;                           // np.multiply(Y, imR, out=J1)
+        const double tn = jn - y;                          // np.subtract(J1, Y, out=T1)
+        a.jnew[jbase + p] = jn;
+        s_ab = s_ab + tn * told;
+        s_bb = s_bb + told * told;
+    }
+    s_ab = wave_sum(s_ab);
+    s_bb = wave_sum(s_bb);
+    if (lane == 0) { sw[0][wave] = s_ab; sw[1][wave] = s_bb; }
+    __syncthreads();
+    if (tid == 0) {
+        double ab = sw[0][0], bb = sw[1][0];
+        for (int w = 1; w < NT / 64; ++w) { ab = ab + sw[0][w]; bb = bb + sw[1][w]; }
+        double *pp = a.partials + ((int64_t)img * a.tiles + t) * 2;
+        pp[0] = ab;
+        pp[1] = bb;
+    }
+}
+
 // ---- Guo et al. variant (deconvolve.py:136-174) ------------------------------
 // ek <- clip(ek * filter2D(image / clip(filter2D(ek, pf), eps, 65535), pb), eps,
 // 65535) with two non-separable K x K projectors (K <= 13) supplied by the host
@@ -1075,6 +1185,54 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
     return MF_OK;
 }
 
+// Lucy-Richardson with a K x K ndimage.convolve kernel on images [i0, i0 + nb)
+template <typename WT>
+int run_lr_conv_batch(const WT *wi, int nb, int i0, int H, int W, int K, const double *h_weights,
+                      int iterations, void *out, int out_f64, unsigned long long *hist, int hist_group,
+                      double *lam_trace, Workspace &ws, hipStream_t s)
+{
+    const int64_t hw = (int64_t)H * W;
+    hipLaunchKernelGGL(lr_init_kernel<WT>, dim3((unsigned)((hw + NT - 1) / NT), (unsigned)nb), dim3(NT), 0,
+                       s, wi, ws.ja, ws.jb, ws.jc, W, hw, ws.jp, ws.js);
+    double *trace = lam_trace ? lam_trace + (int64_t)i0 * iterations : nullptr;
+    hipLaunchKernelGGL(lr_reset_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, ws.lam,
+                       iterations > 0 ? trace : nullptr, (int64_t)iterations, nb);
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.wi = wi;
+    a.partials = ws.partials;
+    a.H = H; a.W = W;
+    a.jp = ws.jp; a.js = ws.js;
+    a.tiles_x = (W + TW - 1) / TW;
+    a.tiles = a.tiles_x * ((H + CONV_TH - 1) / CONV_TH);
+    a.K = K;
+    // scipy/ndimage/_filters.py _correlate_or_convolve: flip, origin -1 on even axes
+    a.c = K / 2 - ((K & 1) ? 0 : 1);
+    for (int i = 0; i < K * K; ++i) {
+        const double w = h_weights[K * K - 1 - i];
+        a.k[i] = std::fabs(w) > DBL_EPSILON ? w : 0.0;    // ni_filters.c: the footprint
+    }
+    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)nb);
+    double *j1 = ws.ja, *j2 = ws.jb, *j3 = ws.jc;
+    for (int it = 0; it < iterations; ++it) {
+        a.j1 = j1; a.j2 = j2; a.j3 = j3;
+        a.jnew = j3;
+        a.lam = ws.lam + (size_t)(it % 3) * nb;
+        a.lam_prev = ws.lam + (size_t)((it + 2) % 3) * nb;
+        hipLaunchKernelGGL(lr_conv2d_kernel<WT>, grid, dim3(NT), 0, s, a);
+        hipLaunchKernelGGL(lr_lambda_kernel, dim3((unsigned)nb), dim3(NT), 0, s, ws.partials, a.tiles, it,
+                           ws.lam + (size_t)((it + 1) % 3) * nb, it + 1 < iterations ? trace : nullptr,
+                           (int64_t)iterations);
+        double *tmp = j3; j3 = j2; j2 = j1; j1 = tmp;
+    }
+    void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
+                        : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
+    hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, j1, W, ws.jp,
+                       ws.js, dst, out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
 template <typename WT>
 int run_guo_batch(const WT *img, int nb, int i0, int H, int W, int K, const double *h_pf,
                   const double *h_pb, int iterations, void *out, int out_f64,
@@ -1153,6 +1311,49 @@ extern "C" int mf_deconvolve_lucyrichardson_guo(const void *image, int image_dty
     return MF_OK;
 }
 
+extern "C" int mf_deconvolve_lucyrichardson_kernel2d(const void *image, int image_dtype, int n_images,
+                                                     int H, int W, int window_size,
+                                                     const double *h_weights, int iterations, void *out,
+                                                     int out_dtype, int64_t *histogram, int hist_group,
+                                                     double *lambdas, int batch, void *workspace,
+                                                     int64_t workspace_bytes, void *stream)
+{
+    if (!image || !out || !workspace || !h_weights) return mf::fail(MF_EINVAL, "null pointer argument");
+    int rc = check_shape(n_images, H, W, batch);
+    if (rc) return rc;
+    if (image_dtype != MF_DTYPE_U16 && image_dtype != MF_DTYPE_F64)
+        return mf::fail(MF_EINVAL, "image dtype %d not u16/f64", image_dtype);
+    if (out_dtype != MF_DTYPE_U16 && out_dtype != MF_DTYPE_F64)
+        return mf::fail(MF_EINVAL, "output dtype %d not u16/f64", out_dtype);
+    if (iterations < 0) return mf::fail(MF_EINVAL, "iteration count %d < 0", iterations);
+    if (window_size < 1 || window_size > CONV_MAXK)
+        return mf::fail(MF_EUNSUPPORTED, "convolution window %d not in 1..%d", window_size, CONV_MAXK);
+    if (histogram && (out_dtype != MF_DTYPE_U16 || hist_group < 1))
+        return mf::fail(MF_EINVAL, "histogram needs uint16 output and hist_group >= 1");
+    Workspace ws;
+    layout_workspace(batch, H, W, reinterpret_cast<unsigned char *>(workspace), ws);
+    if ((int64_t)ws.total > workspace_bytes)
+        return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes", (long long)workspace_bytes,
+                        (long long)ws.total);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t hw = (int64_t)H * W;
+    for (int i0 = 0; i0 < n_images; i0 += batch) {
+        const int nb = n_images - i0 < batch ? n_images - i0 : batch;
+        if (image_dtype == MF_DTYPE_U16)
+            rc = run_lr_conv_batch(reinterpret_cast<const uint16_t *>(image) + i0 * hw, nb, i0, H, W,
+                                   window_size, h_weights, iterations, out, out_dtype == MF_DTYPE_F64,
+                                   reinterpret_cast<unsigned long long *>(histogram), hist_group, lambdas,
+                                   ws, s);
+        else
+            rc = run_lr_conv_batch(reinterpret_cast<const double *>(image) + i0 * hw, nb, i0, H, W,
+                                   window_size, h_weights, iterations, out, out_dtype == MF_DTYPE_F64,
+                                   reinterpret_cast<unsigned long long *>(histogram), hist_group, lambdas,
+                                   ws, s);
+        if (rc) return rc;
+    }
+    return MF_OK;
+}
+
 extern "C" int64_t mf_preprocess_workspace_bytes(int batch, int H, int W)
 {
     int rc = check_shape(0, H, W, batch);
@@ -1189,8 +1390,8 @@ extern "C" int mf_deconvolve_lucyrichardson(const void *image, int image_dtype, 
         return mf::fail(MF_EINVAL, "output dtype %d not u16/f64", out_dtype);
     if (iterations < 0) return mf::fail(MF_EINVAL, "iteration count %d < 0", iterations);
     if (!(window_size & 1))
-        return mf::fail(MF_EUNSUPPORTED, "even window size %d (the reference's ndimage.convolve "
-                        "branch) is not built", window_size);
+        return mf::fail(MF_EUNSUPPORTED, "even window size %d takes the ndimage.convolve branch: "
+                        "mf_deconvolve_lucyrichardson_kernel2d", window_size);
     if (histogram && (out_dtype != MF_DTYPE_U16 || hist_group < 1))
         return mf::fail(MF_EINVAL, "histogram needs uint16 output and hist_group >= 1");
     Taps tp;
@@ -1234,8 +1435,8 @@ extern "C" int mf_preprocess_images(const uint16_t *image, int n_images, int H, 
     if (!(highpass_sigma >= 0)) return mf::fail(MF_EINVAL, "sigma must be >= 0");
     if (decon_iterations < 0) return mf::fail(MF_EINVAL, "iteration count %d < 0", decon_iterations);
     if (!(decon_filter_size & 1))
-        return mf::fail(MF_EUNSUPPORTED, "even window size %d (the reference's ndimage.convolve "
-                        "branch) is not built", decon_filter_size);
+        return mf::fail(MF_EUNSUPPORTED, "even window size %d takes the ndimage.convolve branch: "
+                        "mf_high_pass_filter + mf_deconvolve_lucyrichardson_kernel2d", decon_filter_size);
     if (histogram && hist_group < 1) return mf::fail(MF_EINVAL, "hist_group must be >= 1");
     Taps tp;
     rc = fill_taps(decon_filter_size, decon_sigma, tp);

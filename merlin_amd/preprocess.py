@@ -131,11 +131,19 @@ def deconvolve_lucyrichardson_device(
         image: torch.Tensor, windowSize: int, sigmaG: float,
         iterationCount: int, out_dtype=torch.float64,
         histogram: Optional[torch.Tensor] = None, hist_group: int = 1,
-        batch: Optional[int] = None, return_lambdas: bool = False):
+        batch: Optional[int] = None, return_lambdas: bool = False,
+        gaussianFilter: Optional[np.ndarray] = None):
     """deconvolve_lucyrichardson for images [..., H, W] (uint16 or float64) on
     the GPU.  ``out_dtype`` float64 is the reference's return value, uint16 its
     ``.astype(np.uint16)``.  ``histogram`` (int64 [rows, 65534], zeroed by the
-    caller) receives the counts of image i in row i // hist_group."""
+    caller) receives the counts of image i in row i // hist_group.
+
+    An odd ``windowSize`` is the reference's cv2.GaussianBlur branch, an even
+    one its scipy.ndimage.convolve branch with the matlab_gauss2D kernel
+    (deconvolve.py:102-104, 118-119, 126-128).  ``gaussianFilter`` replaces
+    that kernel (even windows only): np.exp differs in the last bit between
+    numpy builds, so a caller comparing with results made elsewhere passes the
+    kernel that was used there."""
     if image.dtype == torch.uint16:
         dt = _lib.MF_DTYPE_U16
     elif image.dtype == torch.float64:
@@ -157,28 +165,45 @@ def deconvolve_lucyrichardson_device(
                 tuple(histogram.shape) != (rows, HIST_BINS):
             raise ValueError('histogram must be contiguous int64 [{}, {}]'
                              .format(rows, HIST_BINS))
-    with torch.cuda.device(dev):
-        ws = _workspace(dev, batch, H, W)
-        _lib.check(_lib.lib().mf_deconvolve_lucyrichardson(
-            flat.data_ptr(), dt, n, H, W, int(windowSize), float(sigmaG),
-            int(iterationCount), out.data_ptr(),
+    tail = (int(iterationCount), out.data_ptr(),
             _lib.MF_DTYPE_F64 if out_dtype == torch.float64 else _lib.MF_DTYPE_U16,
             None if histogram is None else histogram.data_ptr(), int(hist_group),
-            None if lam is None else lam.data_ptr(), batch, ws.data_ptr(),
-            ws.numel(), _stream_ptr(dev)))
+            None if lam is None else lam.data_ptr(), batch)
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, batch, H, W)
+        if int(windowSize) % 2 == 1:
+            if gaussianFilter is not None:
+                raise ValueError('gaussianFilter only applies to even windows')
+            _lib.check(_lib.lib().mf_deconvolve_lucyrichardson(
+                flat.data_ptr(), dt, n, H, W, int(windowSize), float(sigmaG),
+                *tail, ws.data_ptr(), ws.numel(), _stream_ptr(dev)))
+        else:
+            import ctypes
+            w = int(windowSize)
+            kernel = matlab_gauss2D((w, w), sigmaG) if gaussianFilter is None \
+                else gaussianFilter
+            kernel = np.ascontiguousarray(kernel, dtype=np.float64)
+            if kernel.shape != (w, w):
+                raise ValueError('gaussianFilter must be {} x {}'.format(w, w))
+            _lib.check(_lib.lib().mf_deconvolve_lucyrichardson_kernel2d(
+                flat.data_ptr(), dt, n, H, W, w,
+                kernel.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                *tail, ws.data_ptr(), ws.numel(), _stream_ptr(dev)))
     out = out.reshape(shape)
     return (out, lam) if return_lambdas else out
 
 
 def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
-                              sigmaG: float,
-                              iterationCount: int) -> np.ndarray:
+                              sigmaG: float, iterationCount: int,
+                              gaussianFilter: Optional[np.ndarray] = None
+                              ) -> np.ndarray:
     """Drop-in for merlin.util.deconvolve.deconvolve_lucyrichardson (float64
-    numpy in and out; odd windowSize)."""
+    numpy in and out; odd and even windowSize)."""
     dev = _device()
     t = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float64)).to(dev)
     return deconvolve_lucyrichardson_device(
-        t, windowSize, sigmaG, iterationCount).cpu().numpy()
+        t, windowSize, sigmaG, iterationCount,
+        gaussianFilter=gaussianFilter).cpu().numpy()
 
 
 def matlab_gauss2D(shape=(3, 3), sigma=0.5) -> np.ndarray:
@@ -333,6 +358,18 @@ class DeconvolutionPreprocess(object):
         if histogram:
             hist = torch.zeros(((n + hist_group - 1) // hist_group, HIST_BINS),
                                dtype=torch.int64, device=dev)
+        if int(self.parameters['decon_filter_size']) % 2 == 0:
+            # the reference's ndimage.convolve branch: high-pass, then the
+            # K x K Lucy-Richardson entry point
+            highPassFilterSize = int(2 * np.ceil(2 * self._highPassSigma) + 1)
+            hp = high_pass_filter_device(flat, highPassFilterSize,
+                                         self._highPassSigma)
+            out = deconvolve_lucyrichardson_device(
+                hp, int(self.parameters['decon_filter_size']),
+                self._deconSigma, self._deconIterations,
+                out_dtype=torch.uint16, histogram=hist,
+                hist_group=hist_group, batch=self._batch)
+            return out.reshape(shape), hist
         with torch.cuda.device(dev):
             ws = _workspace(dev, batch, H, W)
             _lib.check(_lib.lib().mf_preprocess_images(

@@ -127,10 +127,35 @@ def run_case(name, deconvolve, imagefilters, image, hp_sigma=3, decon_sigma=2,
         name, dec.max(), int((out16 > 0).sum()), os.path.getsize(path) / 1024))
 
 
+def even_cases(deconvolve, imagefilters):
+    """Even window sizes: the reference's scipy.ndimage.convolve branch
+    (deconvolve.py:102-104, 118-119, 126-128); real scipy, no stub involved in
+    the blur.  ``python oracle/make_preprocess_goldens.py even`` writes only
+    these."""
+    for name, img, size, sigma, its in (
+            ('ppeven_w8', camera_image((72, 100), 30, seed=11), 8, 2, 8),
+            ('ppeven_w4', camera_image((50, 70), 20, seed=12), 4, 1.0, 5),
+            ('ppeven_w12_sat', camera_image((64, 64), 25, seed=13, saturate=True), 12, 0.8, 4)):
+        hp = imagefilters.high_pass_filter(img, 13, 3)
+        dec = deconvolve.deconvolve_lucyrichardson(hp.astype(float), size, sigma, its)
+        # the kernel as this interpreter's numpy makes it (np.exp differs in the
+        # last bit between numpy builds): stored so that the comparison does not
+        # depend on the numpy of whoever runs the tests
+        from merlin.util import matlab
+        kernel = matlab.matlab_gauss2D(shape=(size, size), sigma=sigma)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), image=img, highpass=hp,
+                            kernel=kernel, deconvolved=dec, output=dec.astype(np.uint16),
+                            params=np.array([3, sigma, size, its], dtype=np.float64))
+        print('{:24s} max={:9.1f}'.format(name, dec.max()))
+
+
 def main():
     install_shims()
     from merlin.util import deconvolve, imagefilters
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ['even']:
+        even_cases(deconvolve, imagefilters)
+        return
 
     # one frame of the reference's own test data (raw camera frame)
     import tifffile
@@ -165,6 +190,7 @@ def main():
                             pb=pb, deconvolved=dec, output=dec.astype(np.uint16),
                             params=np.array([3, sigma, size, its], dtype=np.float64))
         print('{:24s} max={:9.1f}'.format(name, dec.max()))
+    even_cases(deconvolve, imagefilters)
 
 
 if __name__ == '__main__':

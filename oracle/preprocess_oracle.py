@@ -98,12 +98,17 @@ def high_pass_filter(image: np.ndarray, windowSize: int,
 
 def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
                               sigmaG: float, iterationCount: int,
-                              trace: list = None) -> np.ndarray:
-    """deconvolve.py:70-133, odd windowSize (the cv2.GaussianBlur branch).
+                              trace: list = None,
+                              gaussianFilter: np.ndarray = None) -> np.ndarray:
+    """deconvolve.py:70-133: odd windowSize = the cv2.GaussianBlur branch, even
+    windowSize = the scipy.ndimage.convolve branch (:102-104, 118-119, 126-128).
     ``trace`` (optional list) receives the acceleration parameter of every
-    iteration."""
-    if windowSize % 2 != 1:
-        raise NotImplementedError('even window sizes take the ndimage path')
+    iteration.  ``gaussianFilter`` replaces the even branch's
+    matlab_gauss2D kernel (np.exp differs in the last bit between numpy builds;
+    the goldens carry the kernel of the interpreter that ran the reference)."""
+    even = windowSize % 2 != 1
+    if even and gaussianFilter is None:
+        gaussianFilter = matlab_gauss2D((windowSize, windowSize), sigmaG)
     image = np.asarray(image, dtype=np.float64)
     eps = np.finfo(float).eps
     Y = np.copy(image)
@@ -122,16 +127,49 @@ def deconvolve_lucyrichardson(image: np.ndarray, windowSize: int,
         Y = J1 - J2                           # cv2.subtract
         Y = J1 * 1.0 + Y * float(lam) + 0.0   # cv2.addWeighted
         np.clip(Y, 0, None, Y)
-        reblurred = gaussian_blur_f64_replicate(Y, windowSize, sigmaG)
+        if even:                              # deconvolve.py:118-119
+            reblurred = ndimage_convolve_constant(Y, gaussianFilter)
+        else:
+            reblurred = gaussian_blur_f64_replicate(Y, windowSize, sigmaG)
         np.clip(reblurred, eps, None, reblurred)
         imR = wI / reblurred                  # cv2.divide (divisor never 0)
         imR += eps
-        imR = gaussian_blur_f64_replicate(imR, windowSize, sigmaG)
+        if even:                              # deconvolve.py:126-128
+            imR = ndimage_convolve_constant(imR, gaussianFilter)
+            imR[imR > 2 ** 16] = 0
+        else:
+            imR = gaussian_blur_f64_replicate(imR, windowSize, sigmaG)
         J2 = J1
         J1 = Y * imR
         T2 = T1
         T1 = J1 - Y
     return J1
+
+
+def ndimage_convolve_constant(img: np.ndarray, weights: np.ndarray) -> np.ndarray:
+    """scipy.ndimage.convolve(img, weights, mode='constant') for a float64 image
+    and a 2-D kernel, restated (scipy/ndimage/_filters.py _correlate_or_convolve
+    + src/ni_filters.c NI_Correlate): the weights are flipped, the origin of an
+    even axis moves by one (so the kernel centre is index size // 2 of the
+    UNFLIPPED kernel), taps with |w| <= DBL_EPSILON are dropped, and the
+    remaining taps are accumulated in row-major order of the flipped kernel into
+    a float64 that starts at 0; outside the image the input is 0.
+    Pinned bit-exact against scipy itself in tests/test_preprocess_oracle.py."""
+    img = np.asarray(img, dtype=np.float64)
+    w = np.asarray(weights, dtype=np.float64)
+    kh, kw = w.shape
+    wf = w[::-1, ::-1]
+    cy = kh // 2 - (0 if kh & 1 else 1)        # centre inside the flipped kernel
+    cx = kw // 2 - (0 if kw & 1 else 1)
+    H, W = img.shape
+    pad = np.zeros((H + kh - 1, W + kw - 1))
+    pad[cy:cy + H, cx:cx + W] = img
+    out = np.zeros((H, W))
+    for ky in range(kh):
+        for kx in range(kw):
+            if abs(wf[ky, kx]) > np.finfo(float).eps:
+                out = out + pad[ky:ky + H, kx:kx + W] * wf[ky, kx]
+    return out
 
 
 def to_uint16(values: np.ndarray) -> np.ndarray:

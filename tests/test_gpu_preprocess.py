@@ -160,7 +160,11 @@ def test_errors(gpu_device):
     from merlin_amd import preprocess as pp
     img = np.zeros((32, 32))
     with pytest.raises(NotImplementedError):
-        pp.deconvolve_lucyrichardson(img, 8, 2, 3)           # ndimage branch
+        pp.deconvolve_lucyrichardson(img, 18, 2, 3)          # ndimage branch: <= 16
+    with pytest.raises(ValueError):
+        pp.deconvolve_lucyrichardson(img, 8, 2, 3, gaussianFilter=np.ones((6, 6)))
+    with pytest.raises(ValueError):
+        pp.deconvolve_lucyrichardson(img, 9, 2, 3, gaussianFilter=np.ones((9, 9)))
     with pytest.raises(NotImplementedError):
         pp.deconvolve_lucyrichardson(img, 15, 2, 3)
     with pytest.raises(NotImplementedError):
@@ -293,6 +297,61 @@ def test_guo_variant(gpu_device):
         pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 15, 2, 2)
     with pytest.raises(NotImplementedError):
         pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 8, 2, 2)
+
+
+def test_even_window_branch(gpu_device):
+    """Even windowSize: the reference's scipy.ndimage.convolve branch
+    (deconvolve.py:102-104, 118-119, 126-128) through
+    mf_deconvolve_lucyrichardson_kernel2d.  Against the reference-made goldens
+    with the kernel the reference used: bit-exact while the acceleration
+    parameter is 0, then to 1e-9 (lambda's sums are added in tile order);
+    against the oracle on other shapes, batches and both input dtypes."""
+    import glob, os
+    import torch
+    from conftest import GOLDEN_DIR
+    from merlin_amd import preprocess as pp
+    names = sorted(os.path.basename(p)[:-4]
+                   for p in glob.glob(os.path.join(GOLDEN_DIR, 'ppeven_*.npz')))
+    assert len(names) == 3
+    for name in names:
+        g = load_pp(name)
+        p = g['p']
+        hp = g['highpass'].astype(np.float64)
+        two = pp.deconvolve_lucyrichardson(hp, p['decon_size'], p['decon_sigma'], 2,
+                                           gaussianFilter=g['kernel'])
+        assert np.array_equal(two, po.deconvolve_lucyrichardson(
+            hp, p['decon_size'], p['decon_sigma'], 2, gaussianFilter=g['kernel']))
+        got = pp.deconvolve_lucyrichardson(hp, p['decon_size'], p['decon_sigma'],
+                                           p['iterations'], gaussianFilter=g['kernel'])
+        check_f64(got, g['deconvolved'])
+        dec16, lam = pp.deconvolve_lucyrichardson_device(
+            torch.from_numpy(g['highpass']).to(gpu_device), p['decon_size'], p['decon_sigma'],
+            p['iterations'], out_dtype=torch.uint16, return_lambdas=True,
+            gaussianFilter=g['kernel'])
+        check_u16(dec16.cpu().numpy(), g['output'])
+        trace = []
+        po.deconvolve_lucyrichardson(hp, p['decon_size'], p['decon_sigma'], p['iterations'],
+                                     trace, gaussianFilter=g['kernel'])
+        np.testing.assert_allclose(lam.cpu().numpy()[0], np.array(trace), rtol=1e-11, atol=1e-14)
+    # odd shapes, a batch of different images, this interpreter's own kernel
+    rng = np.random.default_rng(8)
+    for shape, window, sigma in (((75, 141), 6, 1.5), ((33, 70), 16, 3.0), ((5, 7), 8, 2.0),
+                                 ((64, 200), 2, 0.6)):
+        stack = np.stack([po.high_pass_filter(camera(shape, 12, 40 + i), 13, 3) for i in range(3)])
+        got = pp.deconvolve_lucyrichardson_device(
+            torch.from_numpy(stack).to(gpu_device), window, sigma, 2, batch=2).cpu().numpy()
+        for i in range(3):
+            assert np.array_equal(got[i], po.deconvolve_lucyrichardson(
+                stack[i].astype(np.float64), window, sigma, 2))
+        check_f64(pp.deconvolve_lucyrichardson(stack[0].astype(np.float64), window, sigma, 7),
+                  po.deconvolve_lucyrichardson(stack[0].astype(np.float64), window, sigma, 7))
+    # the preprocess task with an even decon_filter_size
+    g = load_pp('ppeven_w8')
+    task = pp.DeconvolutionPreprocess({'decon_filter_size': 8, 'decon_iterations': 8})
+    out, hist = task.preprocess_device(torch.from_numpy(g['image'][None]).to(gpu_device))
+    check_u16(out[0].cpu().numpy(), g['output'], frac=1e-3)
+    assert np.array_equal(hist[0].cpu().numpy(),
+                          po.pixel_histogram(out.cpu().numpy()[0]).astype(np.int64))
 
 
 def test_release_workspaces(gpu_device):
