@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--fragments', type=int, default=50)
     ap.add_argument('--iterations', type=int, default=3)
+    ap.add_argument('--workers', type=int, default=None)
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
@@ -48,8 +49,10 @@ def main():
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 cur = OptimizeIteration(
-                    codebook, {'fov_per_iteration': args.fragments,
-                               'optimize_background': background},
+                    codebook, dict({'fov_per_iteration': args.fragments,
+                                    'optimize_background': background},
+                                   **({} if args.workers is None
+                                      else {'fragment_workers': args.workers})),
                     fovs=[0, 1], zCount=Z, previousIteration=prev,
                     initialScaleFactors=sf0, imageProvider=provider, device=dev,
                     seed=99 + it).run()

@@ -141,6 +141,9 @@ class OptimizeIteration(object):
         p.setdefault('optimize_background', False)
         p.setdefault('optimize_chromatic_correction', False)
         p.setdefault('crop_width', 0)
+        # fragments in flight on one GPU (worker threads, one stream each); not
+        # a parameter of the reference, which runs one process per fragment
+        p.setdefault('fragment_workers', 4)
         if p['optimize_chromatic_correction']:
             raise NotImplementedError('chromatic correction is out of scope')
         if 'fov_index' in p:
@@ -196,13 +199,78 @@ class OptimizeIteration(object):
         if self._provider is None:
             raise ValueError('imageProvider is required')
         img = self._provider(fovIndex, zIndex)
+        out, vol = self._fragment_on_device(decoder, img, scaleFactors,
+                                            backgrounds)
+        self._last_volume = vol
+        return out
+
+    def _fragment_on_device(self, decoder, img, scaleFactors, backgrounds):
         # region statistics read the traces of decoded pixels only
         vol = decoder.decode_pixels_device(img, scaleFactors, backgrounds,
                                            returnTraces='decoded')
         out = decoder.extract_refactors_device(
             vol, self.parameters['optimize_background'])
-        self._last_volume = vol
-        return out
+        return out, vol
+
+    def _fragment_barcodes(self, vol, fovIndex, zIndex):
+        """optimize.py:116-122: the fragment's barcodes"""
+        p = self.parameters
+        return self._decoder.extract_barcodes(
+            vol, fovIndex, p['crop_width'], zIndex, None, p['area_threshold'],
+            zPlane=0)
+
+    def _run_fragments_threaded(self, mine, scaleFactors, backgrounds, workers,
+                                rf, bgr, seen):
+        """The default fragment function with ``workers`` fragments in flight.
+        A fragment is < 1 ms of GPU work and ~4 ms of host work (the ordered
+        float64 reductions of extract_refactors and the DataFrame), most of it
+        inside numpy / torch calls that release the interpreter lock, so
+        worker threads -- each with its own HIP stream -- overlap one
+        fragment's host work with the others' kernels and copies.  Fragments are
+        independent and every reduction inside one is ordered, so the results
+        do not depend on the scheduling.  The image provider is called from the
+        calling thread, in fragment order; a worker's stream waits for whatever
+        the provider queued on the caller's stream."""
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        import torch
+        p = self.parameters
+        dev = self._decoder._dev()
+        local = threading.local()
+
+        def work(k, frag, img, ready):
+            if not hasattr(local, 'stream'):
+                local.stream = torch.cuda.Stream(dev)
+            fovIndex, zIndex = p['fov_index'][frag]
+            with torch.cuda.device(dev), torch.cuda.stream(local.stream):
+                local.stream.wait_event(ready)
+                out, vol = self._fragment_on_device(
+                    self._decoder, img, scaleFactors, backgrounds)
+                barcodes = self._fragment_barcodes(vol, fovIndex, zIndex)
+                # the volume's buffers were allocated on this stream; it is
+                # idle again before they go back to the allocator
+                local.stream.synchronize()
+            return k, frag, out, barcodes
+
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            pending = []
+            for k, frag in enumerate(mine):
+                fovIndex, zIndex = p['fov_index'][frag]
+                img = self._provider(fovIndex, zIndex)
+                with torch.cuda.device(dev):
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream(dev))
+                pending.append(pool.submit(work, k, frag, img, ready))
+                # bound the images kept alive by fragments not yet started
+                while len(pending) > 2 * workers:
+                    self._store_fragment(pending.pop(0).result(), rf, bgr, seen)
+            for f in pending:
+                self._store_fragment(f.result(), rf, bgr, seen)
+
+    def _store_fragment(self, result, rf, bgr, seen):
+        k, frag, out, barcodes = result
+        rf[k], bgr[k], seen[k] = out
+        self.barcodes[frag] = barcodes
 
     # -------------------------------------------------------------- run --
 
@@ -226,16 +294,25 @@ class OptimizeIteration(object):
         rf = np.zeros((len(mine), self._bits))
         bgr = np.zeros((len(mine), self._bits))
         seen = np.zeros((len(mine), self._codes))
-        for k, frag in enumerate(mine):
+        workers = int(p['fragment_workers'])
+        if self._fragment_fn == self._decode_fragment and workers > 1 \
+                and len(mine) > 1:
+            if self._provider is None:
+                raise ValueError('imageProvider is required')
+            self._decoder._codebook_device()   # built before the threads start
+            self._run_fragments_threaded(mine, scaleFactors, backgrounds,
+                                         workers, rf, bgr, seen)
+            mine_serial = []
+        else:
+            mine_serial = list(enumerate(mine))
+        for k, frag in mine_serial:
             fovIndex, zIndex = p['fov_index'][frag]
             self._last_volume = None
             rf[k], bgr[k], seen[k] = self._fragment_fn(
                 self._decoder, fovIndex, zIndex, scaleFactors, backgrounds)
             if self._last_volume is not None and self._decoder is not None:
-                # optimize.py:116-122: the fragment's barcodes
-                self.barcodes[frag] = self._decoder.extract_barcodes(
-                    self._last_volume, fovIndex, p['crop_width'], zIndex,
-                    None, p['area_threshold'], zPlane=0)
+                self.barcodes[frag] = self._fragment_barcodes(
+                    self._last_volume, fovIndex, zIndex)
                 self._last_volume = None
 
         # one exchange per iteration (every rank used the same previous

@@ -197,6 +197,42 @@ def test_optimize_iterations_match_oracle(gpu_device):
     assert cur.get_scale_factor_history().shape == (3, 16)
 
 
+def test_optimize_fragment_workers_do_not_change_results(gpu_device):
+    """OptimizeIteration runs its fragments on worker threads (four in flight
+    by default); one at a time gives the same refactors, counts and barcode
+    tables, bit for bit."""
+    import torch
+    from merlin_amd import optimize
+    from merlin_amd.synthetic import synthetic_fov
+    rng = np.random.default_rng(3)
+    cb = (rng.random((40, 16)) < 0).astype(int)
+    for row in cb:
+        row[rng.choice(16, 4, replace=False)] = 1
+    cb = np.unique(cb, axis=0)
+    fov = synthetic_fov(cb, 3, 256, 320, 300, 77, gpu_device)
+    init = np.full(16, 400.0)
+    frags = [[0, z] for z in (0, 1, 2, 1, 0, 2, 2)]
+    runs = []
+    for workers in (1, 3):
+        it = optimize.OptimizeIteration(
+            ArrayCodebook(cb), {'fov_index': frags, 'optimize_background': True,
+                                'fragment_workers': workers},
+            initialScaleFactors=init, imageProvider=lambda f, z: fov[:, z],
+            device=gpu_device).run()
+        runs.append(it)
+    a, b = runs
+    assert np.array_equal(a.get_scale_factors(), b.get_scale_factors(), equal_nan=True)
+    assert np.array_equal(a.get_backgrounds(), b.get_backgrounds(), equal_nan=True)
+    assert np.array_equal(a._counts, b._counts) and a._counts.sum() > 50
+    assert np.array_equal(a._refactors, b._refactors, equal_nan=True)
+    assert set(a.barcodes) == set(b.barcodes) == set(range(len(frags)))
+    for k in a.barcodes:
+        assert len(a.barcodes[k]) > 5
+        assert a.barcodes[k].equals(b.barcodes[k])
+    # the same plane drawn twice gives the same table
+    assert a.barcodes[1].equals(a.barcodes[3])
+
+
 def test_run_fovs_from_host_matches_run_fov(gpu_device):
     """Host-resident stacks through the pinned multi-buffered uploader (more
     FOVs than device buffers; pageable numpy, pinned and plain CPU tensors)
