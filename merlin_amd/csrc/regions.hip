@@ -642,7 +642,7 @@ region_stats(const StatsArgs a)
     }
 }
 
-// Onesweep with 9-bit digits (512-thread blocks): a pass costs ~45 us here
+// Onesweep with 9-bit digits: a pass has a fixed cost of tens of us here
 // almost regardless of the element count, so the number of passes is what
 // matters -- 3 instead of 4 for the <= 27-bit pixel keys, 2 instead of 3 for
 // the <= 18-bit region keys.  (rocPRIM's default for ~2e5 elements would be a
@@ -650,8 +650,22 @@ region_stats(const StatsArgs a)
 #ifndef MF_RADIX_BITS
 #define MF_RADIX_BITS 9
 #endif
-using Onesweep9 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<(1 << MF_RADIX_BITS), 8>,
-                                                      rocprim::kernel_config<(1 << MF_RADIX_BITS), 8>,
+// Sort blocks of 512 threads x 12 items.  Per pass over the 6.9 M (root, pixel)
+// pairs of a 7-z FOV with the GPU to itself: 512 x 8: 73 us, 512 x 12: 65,
+// 512 x 16: 71, 256 x 16: 103, 1024 x 6: 55, 1024 x 8: 51, 1024 x 10 / 12: 72-74
+// (dev/time_region_variants.sh).  What counts is the FOV pipeline, where the sort
+// runs beside the next FOV's decode kernel and a block has to fit into the LDS
+// and wave slots that kernel leaves free: 512 x 8: 1.873 ms per FOV, 512 x 10:
+// 1.848, 512 x 12: 1.845, 256 x 16: 1.90, 256 x 24: 1.87, and 2.00-2.06 for every
+// shape with 64 KB of LDS per block (1024 x 6 / 8, 512 x 16) (dev/pipedepth.py).
+#ifndef MF_SORT_BLOCK
+#define MF_SORT_BLOCK (1 << MF_RADIX_BITS)
+#endif
+#ifndef MF_SORT_IPT
+#define MF_SORT_IPT 12
+#endif
+using Onesweep9 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<MF_SORT_BLOCK, MF_SORT_IPT>,
+                                                      rocprim::kernel_config<MF_SORT_BLOCK, MF_SORT_IPT>,
                                                       MF_RADIX_BITS,
                                                       rocprim::block_radix_rank_algorithm::match>;
 using PixelSortConfig =
