@@ -41,6 +41,9 @@ constexpr int ROWS_PER_WAVE = TH / 4;
 constexpr int HIST_BINS = MF_HIST_BINS;
 constexpr double EPS = DBL_EPSILON;      // np.finfo(float).eps, deconvolve.py:89
 
+struct alignas(16) D2 { double x, y; };      // two adjacent columns of one lane
+struct alignas(4) U2 { uint16_t x, y; };
+
 struct Taps {
     double k[2 * MF_PP_MAX_RADIUS + 1];
     uint32_t kfix[2 * MF_PP_MAX_RADIUS + 1];
@@ -319,8 +322,6 @@ __global__ void __launch_bounds__(64) lr_fused_kernel(const LrArgs a)
 // otherwise they shift.  Needs an even image width (a lane's pair is then never
 // split by the right edge) and 16-byte aligned rows; the host falls back to
 // lr_fused_kernel otherwise.  Arithmetic per pixel is unchanged.
-struct alignas(16) D2 { double x, y; };
-struct alignas(4) U2 { uint16_t x, y; };
 template <typename T> struct PairOf;
 template <> struct PairOf<double> { using type = D2; };
 template <> struct PairOf<uint16_t> { using type = U2; };
@@ -627,21 +628,41 @@ __global__ void __launch_bounds__(NT) lr_finalize_kernel(const double *j, int W,
         for (int i = threadIdx.x; i < HIST_LOW; i += NT) low[i] = 0u;
     __syncthreads();
     unsigned long long *row = hist ? hist + (int64_t)((img0 + img) / hist_group) * HIST_BINS : nullptr;
-    const int64_t per = (hw + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(hw, lo + per);
     unsigned zeros = 0;      // most deconvolved pixels are 0: one LDS add per thread, not per pixel
-    for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
-        const int y = (int)(i / W);
-        const double v = src[(int64_t)y * jp + (i - (int64_t)y * W)];
-        if (out_f64) {
-            reinterpret_cast<double *>(out)[(int64_t)img * hw + i] = v;
-        } else {
-            const uint16_t u = to_u16(v);
-            reinterpret_cast<uint16_t *>(out)[(int64_t)img * hw + i] = u;
-            if (hist) {
-                if (u == 0) ++zeros;
-                else if (u < HIST_LOW) atomicAdd(&low[u], 1u);
-                else if (u < 65535) atomicAdd(row + min((int)u, HIST_BINS - 1), 1ull);
+    auto count = [&](uint16_t u) {
+        if (u == 0) ++zeros;
+        else if (u < HIST_LOW) atomicAdd(&low[u], 1u);
+        else if (u < 65535) atomicAdd(row + min((int)u, HIST_BINS - 1), 1ull);
+    };
+    // an even share of the pixels per block, so that pairs never straddle two blocks
+    const int64_t per = (((hw + gridDim.x - 1) / gridDim.x) + 1) & ~int64_t(1);
+    const int64_t lo = min(hw, (int64_t)blockIdx.x * per), hi = min(hw, lo + per);
+    const bool pairs = jp == W && !(hw & 1) && !(js & 1) && !(reinterpret_cast<uintptr_t>(j) & 15)
+        && !(reinterpret_cast<uintptr_t>(out) & 15);
+    if (pairs) {            // dense rows: 16 bytes in, 4 (or 16) bytes out per lane
+        const D2 *src2 = reinterpret_cast<const D2 *>(src);
+        for (int64_t q = (lo >> 1) + threadIdx.x; q < (hi >> 1); q += NT) {
+            const D2 v = src2[q];
+            if (out_f64) {
+                reinterpret_cast<D2 *>(out)[(((int64_t)img * hw) >> 1) + q] = v;
+            } else {
+                U2 u;
+                u.x = to_u16(v.x);
+                u.y = to_u16(v.y);
+                reinterpret_cast<U2 *>(out)[(((int64_t)img * hw) >> 1) + q] = u;
+                if (hist) { count(u.x); count(u.y); }
+            }
+        }
+    } else {                // padded rows or odd sizes
+        for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
+            const unsigned y = (unsigned)i / (unsigned)W;         // hw < 2^31 (check_shape)
+            const double v = src[(int64_t)y * jp + ((unsigned)i - y * (unsigned)W)];
+            if (out_f64) {
+                reinterpret_cast<double *>(out)[(int64_t)img * hw + i] = v;
+            } else {
+                const uint16_t u = to_u16(v);
+                reinterpret_cast<uint16_t *>(out)[(int64_t)img * hw + i] = u;
+                if (hist) count(u);
             }
         }
     }
