@@ -729,6 +729,133 @@ __global__ void __launch_bounds__(NT) high_pass_kernel(const HpArgs a)
     }
 }
 
+// ---- high-pass, streaming form -----------------------------------------------
+// The tiled kernel above re-reads a 12-pixel halo on every side of a 64 x 32
+// tile and pays 39 integer multiply-adds plus 26 LDS reads per pixel: 0.7 ms per
+// 28 frames of 2048 x 2048, i.e. 0.7 TB/s for a 4 B/px filter.  This one streams
+// 256-column strips top to bottom, one wave per strip and segment, four columns
+// per lane (8-byte loads and stores): the row pass reads the lane's window from
+// one LDS row as packed u16 pairs and adds two taps per v_dot2_u32_u16 (the
+// packed taps of the four outputs come from the host), the u32 row sums of the
+// last 2R + 1 rows sit in registers already split into 16-bit halves (rings
+// renamed by unrolling the row loop 2R + 1 times), and the column pass is two
+// exact 32-bit sums, symmetric taps paired (24-bit multiplies; see
+// high_pass_kernel for the rounding).  Same arithmetic, same results.
+constexpr int HPQ = 4;                 // columns per lane
+constexpr int HPW = TW * HPQ;          // strip width
+constexpr int HPH = 8;                 // column halo on either side (>= R, a multiple of 4)
+constexpr int HP_MAXD = MF_PP_MAX_RADIUS + (MF_PP_MAX_RADIUS & 1) + 2;
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+struct HpsArgs {
+    const uint16_t *in;
+    uint16_t *out;
+    int H, W, tiles_x, nseg, nblk, tiles;
+    uint32_t tap[HPQ][HP_MAXD];        // packed taps of output column i over the lane's window
+    uint32_t kfix[2 * MF_PP_MAX_RADIUS + 1];
+};
+
+template <int R>
+__global__ void __launch_bounds__(64, 2) high_pass_stream_kernel(const HpsArgs a)
+{
+    constexpr int RE = R + (R & 1);        // window starts RE columns left of the lane's first
+    constexpr int ND = RE + 2;             // dwords (u16 pairs) in the window
+    constexpr int N = 2 * R + 1;
+    constexpr int OUTW = HPW - 2 * HPH;
+    __shared__ uint32_t srow[HPW / 2 + RE];
+    const int t = xcd_tile(a.tiles);
+    if (t < 0) return;
+    const int lane = threadIdx.x;
+    const int H = a.H, W = a.W;
+    const int sx = t % a.tiles_x, k = t / a.tiles_x;
+    const int y0 = (int)((int64_t)k * a.nblk / a.nseg) * BH;
+    const int rows_out = min((int)((int64_t)(k + 1) * a.nblk / a.nseg) * BH, H) - y0;
+    const int64_t base = (int64_t)blockIdx.y * H * W;
+    const uint16_t *in = a.in + base;
+    const int x0 = sx * OUTW;
+    const int cq = x0 - HPH + HPQ * lane;              // first of the lane's four columns
+    const int cl = clampi(cq, 0, W - HPQ);             // the quad that is loaded for them
+    const bool left = cq < 0, right = cq >= W;         // BORDER_REPLICATE of whole quads
+    const bool out_lane = lane >= HPH / HPQ && lane < TW - HPH / HPQ && cq < W;
+    for (int i = lane; i < HPW / 2 + RE; i += TW)
+        if (i < RE / 2 || i >= RE / 2 + HPW / 2) srow[i] = 0u;     // pads: never written again
+
+    uint2 qin[N], qout[N];
+    auto fetch = [&](int u, int r) {
+        const int yi = clampi(y0 + min(r, rows_out + R - 1), 0, H - 1);
+        qin[u] = *reinterpret_cast<const uint2 *>(in + (int64_t)yi * W + cl);
+        const int yo = y0 + clampi(r - R, 0, rows_out - 1);
+        qout[u] = *reinterpret_cast<const uint2 *>(in + (int64_t)yo * W + cl);
+    };
+    uint32_t rh[HPQ][N], rl[HPQ][N];       // row sums of the last 2R + 1 rows, 16-bit halves
+#pragma unroll
+    for (int i = 0; i < HPQ; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) rh[i][j] = rl[i][j] = 0u;
+
+    const int r_end = rows_out + R;
+#pragma unroll
+    for (int u = 0; u < N; ++u) fetch(u, -R + u);
+    for (int rb = -R; rb < r_end; rb += N) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const int r = rb + u;
+            uint2 q = qin[u];
+            const uint2 c = qout[u];
+            if (left) q.x = q.y = (q.x & 0xffffu) * 0x10001u;
+            if (right) q.x = q.y = (q.y >> 16) * 0x10001u;
+            lds_wave_order();
+            srow[RE / 2 + 2 * lane] = q.x;
+            srow[RE / 2 + 2 * lane + 1] = q.y;
+            lds_wave_order();
+            uint32_t w[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) w[d] = srow[2 * lane + d];
+#pragma unroll
+            for (int i = 0; i < HPQ; ++i) {
+                uint32_t h = 0u;       // taps sum to 65536: fits 32 bits
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    h = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, w[d]),
+                                               __builtin_bit_cast(u16x2, a.tap[i][d]), h, false);
+                rh[i][u] = h >> 16;     // slot u: the row loop is unrolled N times
+                rl[i][u] = h & 0xffffu;
+            }
+            // row sum j (0 = oldest) of the ring now lives in slot (u + 1 + j) % N
+            const int ro = r - R;
+            if (ro >= 0 && ro < rows_out) {
+                MF_UNIFORM_BRANCH();
+                uint32_t o[HPQ];
+#pragma unroll
+                for (int i = 0; i < HPQ; ++i) {
+                    uint32_t shi = __umul24(a.kfix[R], rh[i][(u + 1 + R) % N]);
+                    uint32_t slo = __umul24(a.kfix[R], rl[i][(u + 1 + R) % N]);
+#pragma unroll
+                    for (int j = 1; j <= R; ++j) {
+                        // symmetric taps: k (a + b), k <= 2^15, a + b < 2^17
+                        shi += __umul24(a.kfix[R + j], rh[i][(u + 1 + R + j) % N] + rh[i][(u + 1 + R - j) % N]);
+                        slo += __umul24(a.kfix[R + j], rl[i][(u + 1 + R + j) % N] + rl[i][(u + 1 + R - j) % N]);
+                    }
+                    uint32_t lp = (shi + (slo >> 16) + 0x8000u) >> 16;
+                    if (lp > 65535u) lp = 65535u;
+                    const uint32_t pair = i < 2 ? c.x : c.y;
+                    const uint32_t v = (i & 1) ? pair >> 16 : pair & 0xffffu;
+                    o[i] = lp > v ? 0u : v - lp;
+                }
+                if (out_lane) {
+                    uint2 res;
+                    res.x = o[0] | (o[1] << 16);
+                    res.y = o[2] | (o[3] << 16);
+                    *reinterpret_cast<uint2 *>(a.out + base + (int64_t)(y0 + ro) * W + cq) = res;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(u, r + N);
+        }
+    }
+}
+
 // ---- even windows: the reference's scipy.ndimage.convolve branch -------------
 // deconvolve.py:102-104, 118-119, 126-128: with an even windowSize both blurs of
 // an iteration are ndimage.convolve(x, matlab_gauss2D, mode='constant') -- a
@@ -1123,6 +1250,28 @@ int check_shape(int n, int H, int W, int batch)
     return MF_OK;
 }
 
+template <int R>
+int launch_high_pass_stream(HpsArgs a, int nb, hipStream_t s)
+{
+    static const int slots = wave_slots(high_pass_stream_kernel<R>);
+    a.nseg = choose_segments((int64_t)a.tiles_x * nb, a.nblk, 2 * R, slots);
+    a.tiles = a.tiles_x * a.nseg;
+    const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)nb);
+    hipLaunchKernelGGL(high_pass_stream_kernel<R>, grid, dim3(64), 0, s, a);
+    return MF_OK;
+}
+
+// development builds can switch the streaming high-pass off (MF_HP_STREAM=0)
+bool use_hp_stream()
+{
+#ifdef MF_LR_TUNE
+    static const bool on = !(std::getenv("MF_HP_STREAM") && !std::atoi(std::getenv("MF_HP_STREAM")));
+    return on;
+#else
+    return true;
+#endif
+}
+
 int run_high_pass(const uint16_t *in, int n, int H, int W, int ksize, double sigma, uint16_t *out,
                   hipStream_t s)
 {
@@ -1130,6 +1279,48 @@ int run_high_pass(const uint16_t *in, int n, int H, int W, int ksize, double sig
     int rc = fill_taps(ksize, sigma, h.tp);
     if (rc) return rc;
     h.R = ksize / 2;
+    // streaming kernel: quads of columns must not straddle the image edge or an
+    // 8-byte boundary, and every tap has to fit the 16 bits v_dot2_u32_u16 takes
+    bool stream = use_hp_stream() && h.R >= 1 && h.R <= HPH && W >= HPQ && !(W & 3)
+        && !(reinterpret_cast<uintptr_t>(in) & 7) && !(reinterpret_cast<uintptr_t>(out) & 7);
+    for (int j = 0; j < ksize; ++j) stream = stream && h.tp.kfix[j] < 65536u;
+    if (stream) {
+        const int R = h.R, RE = R + (R & 1);
+        HpsArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.H = H; a.W = W;
+        a.tiles_x = (W + (HPW - 2 * HPH) - 1) / (HPW - 2 * HPH);
+        a.nblk = (H + BH - 1) / BH;
+        std::memcpy(a.kfix, h.tp.kfix, sizeof(a.kfix));
+        // window element e of a lane is column 4 L - RE + e; output i sits at
+        // column 4 L + i, its tap j at column 4 L + i - R + j
+        for (int i = 0; i < HPQ; ++i)
+            for (int d = 0; d < RE + 2; ++d) {
+                uint32_t pair = 0;
+                for (int half = 0; half < 2; ++half) {
+                    const int j = 2 * d + half - i - (RE - R);
+                    if (j >= 0 && j <= 2 * R) pair |= h.tp.kfix[j] << (16 * half);
+                }
+                a.tap[i][d] = pair;
+            }
+        for (int i0 = 0; i0 < n; i0 += 65535) {
+            const int nb = n - i0 < 65535 ? n - i0 : 65535;
+            a.in = in + (int64_t)i0 * H * W;
+            a.out = out + (int64_t)i0 * H * W;
+            switch (R) {
+            case 1: launch_high_pass_stream<1>(a, nb, s); break;
+            case 2: launch_high_pass_stream<2>(a, nb, s); break;
+            case 3: launch_high_pass_stream<3>(a, nb, s); break;
+            case 4: launch_high_pass_stream<4>(a, nb, s); break;
+            case 5: launch_high_pass_stream<5>(a, nb, s); break;
+            case 6: launch_high_pass_stream<6>(a, nb, s); break;
+            case 7: launch_high_pass_stream<7>(a, nb, s); break;
+            default: launch_high_pass_stream<8>(a, nb, s); break;
+            }
+        }
+        MF_HIP_CHECK(hipGetLastError());
+        return MF_OK;
+    }
     h.H = H; h.W = W;
     h.tiles_x = (W + TW - 1) / TW;
     h.tiles = h.tiles_x * ((H + TH - 1) / TH);
