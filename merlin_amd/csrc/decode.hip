@@ -5,28 +5,37 @@
 //
 // One workgroup (256 threads = 4 waves) owns a 64 x (4*PPT) pixel tile; lane =
 // column and every thread carries PPT vertically adjacent pixels, so each
-// wave-level store is one contiguous row segment.
+// wave-level store is one contiguous row segment.  Workgroups are persistent
+// (32 per CU, tiles in contiguous runs per XCD) and sized for 3 waves per SIMD
+// at <= 16 bits (<= 168 VGPRs; 2 waves and 2 rows per thread above 16 bits).
 //
-//  * Low-pass: bits are staged four at a time.  Every thread pulls 16-byte
+//  * Low-pass: bits are staged GROUP (4) at a time.  Every thread pulls 16-byte
 //    windows of the u16 rows straight from global memory (prefetched into
-//    registers one group ahead), does the horizontal pass in registers with
-//    exact u32 arithmetic and parks the u32 row sums in LDS; after one barrier
-//    each thread reads its column of row sums back and finishes the vertical
-//    pass with two exact 32-bit sums (the 48-bit total is split into 16-bit
-//    halves).  The stack is read from HBM once.
+//    registers one group ahead; a window's address is a wave-uniform base plus
+//    a 32-bit per-task offset computed once per tile -- 64-bit per-task
+//    addresses hoisted out of the tile loop were what kept the kernel at two
+//    waves per SIMD), does the horizontal pass in registers with
+//    v_dot2_u32_u16 (two exact taps per instruction on the packed u16 pairs of
+//    a window dword) and parks the u32 row sums in LDS; after one barrier each
+//    thread reads its column of row sums back and finishes the vertical pass:
+//    the 48-bit sum as three exact float64 FMAs, (V + 2^31) >> 32 as
+//    trunc(fma(V, 2^-32, 0.5)).  The stack is read from HBM once.
 //  * Scale / background / magnitude / normalise stay in registers
-//    (x[PPT][MAXB]), in numpy's float32 operation order.
+//    (x[PPT][MAXB]), in numpy's float32 operation order; the two divisions are
+//    exact IEEE quotients from the rounded reciprocal and two residual steps.
 //  * Nearest codeword: MERFISH codebooks are binary, so the score of codeword n
 //    is v_n * sum_{on bits} x_b - |c_n|^2/2.  The sum over on-bits is a
-//    [codewords x bits] x [bits x pixels] product with a 0/1 matrix: it runs on
+//    [codewords x bits] x [bits x pixels] product with a 0/-t matrix: it runs on
 //    the matrix cores (v_mfma_f32_32x32x16_bf16) with x split exactly into
 //    three bf16 terms, so the products are exact and only the float32
-//    accumulation rounds.  Each lane keeps a running (best, second, argbest)
-//    over its accumulator registers; the two lanes that share a pixel merge
-//    through v_permlane32_swap.  The winner's distance is recomputed in
-//    float64 exactly as the reference does, and a pixel whose top two scores
-//    are closer than TIE_EPS is re-decided by an exact float64 scan whenever it
-//    could pass the distance threshold.
+//    accumulation rounds.  The accumulator is the key (a float that grows with
+//    the distance); each lane keeps the running minimum -- and the runner-up
+//    unless the codebook's minimum distance rules a second candidate out
+//    (EXCL) -- over its accumulator registers, 32-codeword tiles one after the
+//    other; the two lanes that share a pixel merge through v_permlane32_swap.
+//    The winner's distance is recomputed in float64 exactly as the reference
+//    does, and a pixel whose top two keys are closer than TIE_EPS is re-decided
+//    by an exact float64 scan whenever it could pass the distance threshold.
 //
 // Built with -ffp-contract=off: every float op below is the single IEEE
 // operation it is written as; fused multiply-adds are explicit fmaf() calls.
