@@ -30,21 +30,24 @@ def algorithmic_bytes_per_pixel(iterations: int = 20) -> int:
     (26), every later one J1, J2, J3 and the observed image (34), hand-over to
     uint16 10."""
     return 4 + sum(min(10 + 8 * i, 34) for i in range(iterations)) + 10
-_WORKSPACE_TARGET = 4 << 30
+_WORKSPACE_TARGET = 16 << 30
 
 
 def default_batch(H: int, W: int) -> int:
-    """Images deconvolved per launch: about 4 GiB of workspace (30 frames of
-    2048 x 2048), between 1 and 64.  Measured per 2048 x 2048 frame: 0.80 ms at
-    batch 28, 0.85 at 14, 0.89 at 7, 1.6 at 1 (too few waves to fill the chip,
-    and every launch ends with a partly filled last round of strips)."""
-    return max(1, min(64, _WORKSPACE_TARGET // (_BYTES_PER_PIXEL * H * W)))
+    """Images deconvolved per launch: up to 16 GiB of workspace (26 B per pixel
+    and image), between 1 and 128 -- the 112 frames of a 7-z 16-bit FOV of
+    2048 x 2048 go through in one batch (12 GB).  Measured per 2048 x 2048
+    frame (r02, 112 frames): 0.609 ms at batch 112, 0.614 at 56, 0.625 at 28,
+    0.647 at 16, 1.5 at 1 (too few waves to fill the chip; every launch ends
+    with a partly filled round of strips, and short batches cut the frames
+    into more segments with more halo rows)."""
+    return max(1, min(128, _WORKSPACE_TARGET // (_BYTES_PER_PIXEL * H * W)))
 
 
 def even_batch(n: int, H: int, W: int, batch: Optional[int] = None) -> int:
     """Batch size for n frames: the default (or given) size evened out so that
-    the last launch is as full as the others (112 frames -> 4 x 28, not
-    3 x 30 + 22)."""
+    the last launch is as full as the others (300 frames -> 3 x 100, not
+    2 x 128 + 44)."""
     if batch is None:
         batch = default_batch(H, W)
     batch = max(1, min(int(batch), max(n, 1)))
@@ -66,7 +69,7 @@ def _stream_ptr(device):
 
 
 # One workspace per (device, stream), reused by every call on that stream (up
-# to ~4 GiB each at the default batch).  release_workspaces() returns them to
+# to ~12 GiB each at the default batch).  release_workspaces() returns them to
 # torch's allocator; a long-lived process that preprocesses on many side
 # streams should call it when a stream retires.
 _workspaces = {}
