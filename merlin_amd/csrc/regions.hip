@@ -225,6 +225,7 @@ ccl_flatten(int32_t *L, int n, unsigned long long *counts)
         int4 v = L4[q];
         if ((v.x & v.y & v.z & v.w) < 0) continue;      // four unassigned pixels
         int *e = reinterpret_cast<int *>(&v);
+        bool changed = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = e[k];
@@ -232,12 +233,14 @@ ccl_flatten(int32_t *L, int n, unsigned long long *counts)
                 int r = p;
                 int t = L[r];
                 while (t != r) { r = t; t = L[r]; }
+                changed |= r != p;
                 e[k] = r;
                 ++fg;
                 roots += r == 4 * q + k;
             }
         }
-        L4[q] = v;
+        // most components lie inside one tile and left ccl_tile with their final label
+        if (changed) L4[q] = v;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // tail
         const int i = (n4 << 2) + threadIdx.x;
