@@ -64,6 +64,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 __device__ __forceinline__ double load_wi(const uint16_t *p, int64_t i) { return (double)p[i]; }
 __device__ __forceinline__ double load_wi(const double *p, int64_t i) { return p[i]; }
 
+// float64 -> uint16 the way numpy's astype does on x86: cvttsd2si to int32
+// (0x80000000 when out of range or NaN), low 16 bits (preprocess.py:139)
+__device__ __forceinline__ uint16_t to_u16(double v)
+{
+    if (!(fabs(v) < 2147483648.0)) return 0;
+    return (uint16_t)((int32_t)v & 0xffff);
+}
+
 // Y of the current iteration (deconvolve.py:112-114): cv2.subtract,
 // cv2.addWeighted(J1, 1, Y, lambda, 0), clip at 0
 __device__ __forceinline__ double make_y(double j1, double j2, double lam)
@@ -82,6 +90,10 @@ struct LrArgs {
     const double *lam;       // [n] lambda of this iteration
     const double *lam_prev;  // [n] lambda of the previous iteration
     double *partials;        // [n][nblk][tiles_x][2]
+    // last iteration of a uint16 run (LAST): the hand-over is written instead of J1'
+    uint16_t *out16;               // [n][HW]
+    unsigned long long *hist;      // [rows][HIST_BINS] or NULL
+    int hist_group, img0;
     int H, W;
     int jp;                  // row pitch of the J buffers, in doubles
     int64_t js;              // frame stride of the J buffers, in doubles
@@ -332,7 +344,12 @@ template <> struct PairOf<uint16_t> { using type = U2; };
 // no initialisation pass over the three buffers): iteration 0 takes J1 = J2 =
 // J3 from the observed image, iteration 1 J2 = J3, iteration 2 J3; from
 // iteration 3 on every operand comes from its buffer.
-template <int R, int P, int U, int MODE, typename WT>
+// LAST: the run's final iteration when the caller wants uint16: J1' goes through
+// numpy's float64 -> uint16 cast straight into the output (and into the pixel
+// histogram: zeros are counted per lane, the few per cent of non-zero pixels by
+// global atomics), the lambda sums are skipped, and no hand-over pass re-reads
+// the image.
+template <int R, int P, int U, int MODE, bool LAST, typename WT>
 __global__ void __launch_bounds__(64, 2) lr_fused2_kernel(const LrArgs a)
 {
     using WP = typename PairOf<WT>::type;
@@ -396,6 +413,9 @@ __global__ void __launch_bounds__(64, 2) lr_fused2_kernel(const LrArgs a)
 #pragma unroll
     for (int j = 0; j < N; ++j) r1x[j] = r1y[j] = r2x[j] = r2y[j] = 0.0;
     double ab0 = 0.0, ab1 = 0.0, bb0 = 0.0, bb1 = 0.0, last_x = 0.0, last_y = 0.0;
+    unsigned zeros = 0;
+    unsigned long long *hrow =
+        LAST && a.hist ? a.hist + (int64_t)((a.img0 + img) / a.hist_group) * HIST_BINS : nullptr;
 
     // OpenCV RowFilter over the values the lane read: s = k[0] S[0]; s += k[j] S[j]
     auto row_pass = [&](const double *v, int first) {
@@ -526,21 +546,45 @@ __global__ void __launch_bounds__(64, 2) lr_fused2_kernel(const LrArgs a)
                 D2 jn;
                 jn.x = yo.x * ox;                               // np.multiply(Y, imR, out=J1)
                 jn.y = yo.y * oy;
-                const double tnx = jn.x - yo.x, tny = jn.y - yo.y;      // np.subtract(J1, Y, out=T1)
-                if (out_lane) *reinterpret_cast<D2 *>(a.jnew + base + (int64_t)(y0 + ro) * JP + gx) = jn;
-                // cv2.multiply(T1, T2) summed; lanes that own no output are dropped at the flush
-                ab0 = ab0 + tnx * to.x;
-                ab1 = ab1 + tny * to.y;
-                bb0 = bb0 + to.x * to.x;
-                bb1 = bb1 + to.y * to.y;
-                if (((ro + 1) & (BH - 1)) == 0 || ro == rows_out - 1) {
-                    store_partial(a, img, (y0 + ro) / BH, sx, lane, out_lane ? ab0 + ab1 : 0.0,
-                                  out_lane ? bb0 + bb1 : 0.0);
-                    ab0 = ab1 = bb0 = bb1 = 0.0;
+                if constexpr (LAST) {
+                    if (out_lane) {
+                        U2 u;
+                        u.x = to_u16(jn.x);
+                        u.y = to_u16(jn.y);
+                        *reinterpret_cast<U2 *>(a.out16 + ((int64_t)img * H + (y0 + ro)) * W + gx) = u;
+                        if (hrow) {
+                            // preprocess.py:114-129: bins of np.arange(0, 65535), 65535 outside
+                            if (u.x == 0) ++zeros;
+                            else if (u.x < 65535) atomicAdd(hrow + min((int)u.x, HIST_BINS - 1), 1ull);
+                            if (u.y == 0) ++zeros;
+                            else if (u.y < 65535) atomicAdd(hrow + min((int)u.y, HIST_BINS - 1), 1ull);
+                        }
+                    }
+                } else {
+                    const double tnx = jn.x - yo.x, tny = jn.y - yo.y;  // np.subtract(J1, Y, out=T1)
+                    if (out_lane)
+                        *reinterpret_cast<D2 *>(a.jnew + base + (int64_t)(y0 + ro) * JP + gx) = jn;
+                    // cv2.multiply(T1, T2) summed; lanes that own no output are dropped at the flush
+                    ab0 = ab0 + tnx * to.x;
+                    ab1 = ab1 + tny * to.y;
+                    bb0 = bb0 + to.x * to.x;
+                    bb1 = bb1 + to.y * to.y;
+                    if (((ro + 1) & (BH - 1)) == 0 || ro == rows_out - 1) {
+                        store_partial(a, img, (y0 + ro) / BH, sx, lane, out_lane ? ab0 + ab1 : 0.0,
+                                      out_lane ? bb0 + bb1 : 0.0);
+                        ab0 = ab1 = bb0 = bb1 = 0.0;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                  // as in lr_fused_kernel
             fetch(u, r + P);
+        }
+    }
+    if constexpr (LAST) {
+        if (hrow) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zeros += __shfl_down(zeros, off, 64);
+            if (lane == 0 && zeros) atomicAdd(hrow, (unsigned long long)zeros);
         }
     }
 }
@@ -602,14 +646,6 @@ __global__ void __launch_bounds__(NT) lr_lambda_kernel(const double *partials, i
         lam_next[img] = l;
         if (lam_trace) lam_trace[(int64_t)img * trace_stride + iter + 1] = l;
     }
-}
-
-// float64 -> uint16 the way numpy's astype does on x86: cvttsd2si to int32
-// (0x80000000 when out of range or NaN), low 16 bits (preprocess.py:139)
-__device__ __forceinline__ uint16_t to_u16(double v)
-{
-    if (!(fabs(v) < 2147483648.0)) return 0;
-    return (uint16_t)((int32_t)v & 0xffff);
 }
 
 constexpr int HIST_LOW = 8192;       // bins kept in LDS; the rest go to global atomics
@@ -1181,6 +1217,8 @@ int launch_fused(LrArgs a, int n, hipStream_t s)
     return MF_OK;
 }
 
+constexpr int MODE_LAST = 1 << 20;     // launch_fused2: general operands + fused hand-over
+
 // prefetch depth P and unroll U of the two-column kernel per radius: U is a
 // multiple of 2R + 1 where that keeps the code small (rings rotate by renaming)
 template <int R> struct Fused2Shape {
@@ -1193,15 +1231,18 @@ template <int R, typename WT>
 int launch_fused2(LrArgs a, int n, int mode, hipStream_t s)
 {
     constexpr int P = Fused2Shape<R>::P, U = Fused2Shape<R>::U;
-    static const int slots = wave_slots(lr_fused2_kernel<R, P, U, 3, WT>);
+    static const int slots = wave_slots(lr_fused2_kernel<R, P, U, 3, false, WT>);
     a.nseg = choose_segments((int64_t)a.tiles_x * n, a.nblk, 4 * R, slots);
     a.tiles = a.tiles_x * a.nseg;
     const dim3 grid((unsigned)(((a.tiles + 7) >> 3) << 3), (unsigned)n);
     switch (mode) {
-    case 0: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 0, WT>), grid, dim3(64), 0, s, a); break;
-    case 1: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 1, WT>), grid, dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 2, WT>), grid, dim3(64), 0, s, a); break;
-    default: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 3, WT>), grid, dim3(64), 0, s, a); break;
+    case 0: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 0, false, WT>), grid, dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 1, false, WT>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 2, false, WT>), grid, dim3(64), 0, s, a); break;
+    case MODE_LAST:
+        hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 3, true, WT>), grid, dim3(64), 0, s, a);
+        break;
+    default: hipLaunchKernelGGL((lr_fused2_kernel<R, P, U, 3, false, WT>), grid, dim3(64), 0, s, a); break;
     }
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
@@ -1376,21 +1417,34 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
     a.tiles_x = (W + strip_w - 1) / strip_w;
     a.nblk = (H + BH - 1) / BH;
     a.tp = tp;
+    void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
+                        : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
+    // uint16 output, an operand set without special cases (iteration >= 3) and
+    // 4-byte aligned pairs: the last iteration writes the hand-over itself
+    const bool fuse_last = pairs && !out_f64 && iterations >= 4 && !(reinterpret_cast<uintptr_t>(dst) & 3);
+    a.out16 = reinterpret_cast<uint16_t *>(dst);
+    a.hist = hist;
+    a.hist_group = hist_group > 0 ? hist_group : 1;
+    a.img0 = i0;
     double *j1 = ws.ja, *j2 = ws.jb, *j3 = ws.jc;
     for (int it = 0; it < iterations; ++it) {
         a.j1 = j1; a.j2 = j2; a.j3 = j3;
         a.jnew = j3;
         a.lam = ws.lam + (size_t)(it % 3) * nb;
         a.lam_prev = ws.lam + (size_t)((it + 2) % 3) * nb;
-        int rc = dispatch_fused<WT>(R, pairs, a, nb, it, s);
+        // the last iteration of a uint16 run writes the hand-over itself
+        const bool last = fuse_last && it + 1 == iterations;
+        int rc = dispatch_fused<WT>(R, pairs, a, nb, last ? MODE_LAST : it, s);
         if (rc) return rc;
+        if (last) {
+            MF_HIP_CHECK(hipGetLastError());
+            return MF_OK;
+        }
         hipLaunchKernelGGL(lr_lambda_kernel, dim3((unsigned)nb), dim3(NT), 0, s, ws.partials,
                            a.nblk * a.tiles_x, it, ws.lam + (size_t)((it + 1) % 3) * nb,
                            it + 1 < iterations ? trace : nullptr, (int64_t)iterations);
         double *tmp = j3; j3 = j2; j2 = j1; j1 = tmp;     // (J1, J2, J3) <- (J1', J1, J2)
     }
-    void *dst = out_f64 ? (void *)(reinterpret_cast<double *>(out) + (int64_t)i0 * hw)
-                        : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
     hipLaunchKernelGGL(lr_finalize_kernel, dim3(HIST_BLOCKS, (unsigned)nb), dim3(NT), 0, s, j1, W, ws.jp,
                        ws.js, dst, out_f64, hw, out_f64 ? nullptr : hist, hist_group, i0);
     MF_HIP_CHECK(hipGetLastError());

@@ -27,9 +27,16 @@ def algorithmic_bytes_per_pixel(iterations: int = 20) -> int:
     """HBM bytes per pixel the preprocess stage has to move:
     high-pass 4, Lucy-Richardson iteration 0 reads the observed image and
     writes J (10), iteration 1 also reads J1 (18), iteration 2 J1 and J2
-    (26), every later one J1, J2, J3 and the observed image (34), hand-over to
-    uint16 10."""
-    return 4 + sum(min(10 + 8 * i, 34) for i in range(iterations)) + 10
+    (26), every later one J1, J2, J3 and the observed image (34); the last one
+    writes the uint16 hand-over instead of J (28) from four iterations on,
+    below that a separate hand-over pass reads J and writes uint16 (10)."""
+    per_iteration = [min(10 + 8 * i, 34) for i in range(iterations)]
+    if iterations >= 4:
+        per_iteration[-1] -= 6
+        return 4 + sum(per_iteration)
+    return 4 + sum(per_iteration) + 10
+
+
 _WORKSPACE_TARGET = 16 << 30
 
 
