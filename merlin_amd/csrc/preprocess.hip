@@ -1188,9 +1188,9 @@ int wave_slots(K kernel)
 // takes about as long as a full one (a wave alone is bound by its own latency:
 // measured 1.39 us per row at half occupancy against 1.64 at full), so with one
 // fixed height (r01: 128 rows) up to a fifth of a launch was spent there.
-// Cost: mean rows per segment x rounds, rounded up.  Measured at 28 frames of
-// 2048 x 2048 (19 strips, 2048 slots), ms per frame: 7 segments 0.665, 11
-// 0.651, 15 0.652, 16 0.659, 19 0.697; the rule picks 11.
+// Cost: rows of the longest segment x rounds, rounded up.  Measured at 28 frames
+// of 2048 x 2048 (19 strips, 2048 slots), ms per frame: 7 segments 0.665, 11
+// 0.651, 15 0.652, 16 0.659, 19 0.697; the rule picks 11 (and 8 at 112 frames).
 int choose_segments(int64_t strips, int nblk, int halo, int slots)
 {
 #ifdef MF_LR_TUNE
@@ -1203,7 +1203,10 @@ int choose_segments(int64_t strips, int nblk, int halo, int slots)
     int best = 1;
     double best_cost = 0.0;
     for (int n = 1; n <= most; ++n) {
-        const double rows = (double)nblk * BH / n + halo;
+        // the longest segment sets the length of a round: counts that cut the
+        // frame into equal segments win (112 frames: 8 -> 0.578 ms per frame,
+        // 16 -> 0.581, 11 -> 0.588, 10 / 12 -> 0.598, 14 -> 0.619)
+        const double rows = (double)((nblk + n - 1) / n) * BH + halo;
         const int64_t waves = strips * n;
         const double cost = rows * (double)((waves + slots - 1) / slots);
         if (n == 1 || cost < best_cost) { best = n; best_cost = cost; }
