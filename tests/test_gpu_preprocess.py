@@ -299,6 +299,33 @@ def test_guo_variant(gpu_device):
         pp.deconvolve_lucyrichardson_guo(np.zeros((20, 20)), 8, 2, 2)
 
 
+@pytest.mark.parametrize('hist_group', [1, 3])
+def test_fused_handover_histogram_counts_every_pixel(gpu_device, hist_group):
+    """The last iteration writes the uint16 hand-over and the histogram itself
+    (zeros per lane, values below 256 per wave in LDS, the rest by global
+    atomics): on noisy frames with many non-zero and some large values the
+    histogram must be exactly the histogram of the output, per row group, and
+    the output must equal the unfused path's (float64 result cast on the host)."""
+    import torch
+    from merlin_amd import preprocess as pp
+    rng = np.random.default_rng(21)
+    frames = np.stack([camera((96, 200), 60, 70 + i) for i in range(6)])
+    frames = np.clip(frames.astype(np.int64) + rng.integers(-40, 40, frames.shape), 0, 65535
+                     ).astype(np.uint16)
+    task = pp.DeconvolutionPreprocess({'decon_iterations': 6}, batch=4)
+    out, hist = task.preprocess_device(torch.from_numpy(frames).to(gpu_device),
+                                       hist_group=hist_group)
+    out, hist = out.cpu().numpy(), hist.cpu().numpy()
+    assert hist.shape == (6 // hist_group, 65534)
+    for row in range(6 // hist_group):
+        block = out[row * hist_group:(row + 1) * hist_group]
+        assert np.array_equal(hist[row], po.pixel_histogram(block).astype(np.int64))
+    assert (out > 0).mean() > 0.05 and (out >= 256).sum() > 100
+    hp = pp.high_pass_filter_device(torch.from_numpy(frames).to(gpu_device), 13, 3)
+    dec = pp.deconvolve_lucyrichardson_device(hp, 9, 2, 6).cpu().numpy()
+    assert np.array_equal(out, po.to_uint16(dec))
+
+
 def test_even_window_branch(gpu_device):
     """Even windowSize: the reference's scipy.ndimage.convolve branch
     (deconvolve.py:102-104, 118-119, 126-128) through
