@@ -21,10 +21,10 @@ def T(f, n=5):
 ms, vol = T(lambda: task.decode_fov_device(img, sf, bg)); print('decode_kernel ms %.2f' % ms)
 L = _lib.lib()
 Z,H,W = vol.shape
-labels = torch.empty((Z,H,W), dtype=torch.int32, device=dev); counts = torch.zeros(2, dtype=torch.int64, device=dev)
+labels = torch.empty((Z,H,W), dtype=torch.int32, device=dev); counts = torch.zeros(130, dtype=torch.int64, device=dev)
 sp = torch.cuda.current_stream().cuda_stream
 ms,_ = T(lambda: L.mf_label_components(vol.decoded.data_ptr(), Z,H,W,0, labels.data_ptr(), counts.data_ptr(), sp)); print('label ms %.2f' % ms, counts.cpu().tolist())
-n_pix, n_reg = counts.cpu().tolist()
+n_pix, n_reg = counts.cpu().tolist()[:2]
 B = 16
 rec = torch.empty((n_reg, 12), dtype=torch.float64, device=dev); inten = torch.empty((n_reg, B), dtype=torch.float32, device=dev)
 wsb = L.mf_region_workspace_bytes(Z,H,W,n_pix,n_reg); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)

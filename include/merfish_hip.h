@@ -133,8 +133,14 @@ int mf_decode_pixels(const void *image, int image_dtype,
  *
  *   labels  int32 [Z,H,W]: linear index (z*H*W + y*W + x) of the first pixel
  *           of the component in raster order; -1 for unassigned pixels
- *   counts  int64 [2] (device): counts[0] = assigned pixels, counts[1] =
- *           components.  The caller reads it back to size the tables below. */
+ *   counts  int64 [MF_LABEL_COUNTS_LEN] (device): counts[0] = assigned pixels,
+ *           counts[1] = components; the caller reads these two back to size
+ *           the tables below.  The rest is scratch: the workgroups add their
+ *           partial counts into 64 slots, because thousands of atomics on one
+ *           address serialise (17 ns each: a third of the labelling's last
+ *           kernel), and a one-wave kernel sums the slots. */
+#define MF_LABEL_COUNT_SLOTS 64
+#define MF_LABEL_COUNTS_LEN (2 + 2 * MF_LABEL_COUNT_SLOTS)
 int mf_label_components(const int16_t *decoded, int Z, int H, int W,
                         int conn3d, int32_t *labels, int64_t *counts,
                         void *stream);

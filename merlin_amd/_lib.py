@@ -24,6 +24,7 @@ MF_DECODE_TRACES_DECODED_ONLY = 1
 MF_DECODE_KEEP_RUNNER_UP = 2
 MF_PP_MAX_RADIUS = 8
 MF_HIST_BINS = 65534
+MF_LABEL_COUNTS_LEN = 2 + 2 * 64
 MF_FRAME_STATIC_MAX_ROWS = 1048576
 
 # every symbol include/merfish_hip.h declares

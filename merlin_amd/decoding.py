@@ -445,12 +445,13 @@ class PixelBasedDecoder(object):
         with torch.cuda.device(dev):
             sp = _stream_ptr(dev)
             labels = torch.empty((Z, H, W), dtype=torch.int32, device=dev)
-            counts = torch.empty(2, dtype=torch.int64, device=dev)
+            counts = torch.empty(_lib.MF_LABEL_COUNTS_LEN, dtype=torch.int64,
+                                 device=dev)
             _lib.check(L.mf_label_components(
                 vol.decoded.data_ptr(), Z, H, W, int(is3D),
                 labels.data_ptr(), counts.data_ptr(), sp))
             hcounts = self._pinned((2,), torch.int64)
-            hcounts.copy_(counts, non_blocking=True)
+            hcounts.copy_(counts[:2], non_blocking=True)
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(dev))
         return (labels, counts, hcounts, done)

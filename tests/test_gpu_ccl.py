@@ -17,12 +17,12 @@ def _label_gpu(dec, conn3d, dev):
     Z, H, W = dec.shape
     d = torch.from_numpy(np.ascontiguousarray(dec)).to(dev)
     labels = torch.empty((Z, H, W), dtype=torch.int32, device=dev)
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    counts = torch.zeros(_lib.MF_LABEL_COUNTS_LEN, dtype=torch.int64, device=dev)
     _lib.check(L.mf_label_components(
         d.data_ptr(), Z, H, W, int(conn3d), labels.data_ptr(),
         counts.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
     torch.cuda.synchronize(dev)
-    return labels.cpu().numpy(), counts.cpu().numpy()
+    return labels.cpu().numpy(), counts.cpu().numpy()[:2]
 
 
 def _label_ref(dec, conn3d):
