@@ -201,27 +201,29 @@ __device__ __forceinline__ void merge_pixel(const int16_t *__restrict__ dec, int
     }
 }
 
-// Links across tile edges.  blockIdx.y < n_edge_rows: the pixels of a tile's
-// top row (y = 32 k, k >= 1); else the pixels of the tiles' left and right
-// columns (x = 64 k and 64 k + 63), one thread per (row, column) pair.  A link
-// that stays inside a tile is found already made and costs two label loads.
+// Links across tile edges, one thread per edge pixel of plane blockIdx.y: first
+// the pixels of the tiles' top rows (y = 32 k, k >= 1), then the pixels of the
+// tiles' left and right columns (x = 64 k and 64 k + 63).  A link that stays
+// inside a tile is found already made and costs two label loads.  (A flat index:
+// the earlier 3-D grid launched 31 808 workgroups per 7-z FOV, most of them empty.)
 __global__ void __launch_bounds__(NT)
 ccl_border(const int16_t *__restrict__ dec, int32_t *L, int H, int W, int n_edge_rows,
            int n_edge_cols)
 {
-    const int z = blockIdx.z;
-    const int t = blockIdx.x * NT + threadIdx.x;
-    if ((int)blockIdx.y < n_edge_rows) {
-        if (t < W) merge_pixel(dec, L, t, ((int)blockIdx.y + 1) * CT_H, z, H, W);
-    } else {
-        const int row0 = ((int)blockIdx.y - n_edge_rows) * NT;   // NT rows per block row
-        // thread t of the x-blocks: column pair index, row inside the slab
-        const int col = t % n_edge_cols, y = row0 + t / n_edge_cols;
-        const int x = (col >> 1) * CT_W + (col & 1 ? CT_W - 1 : 0);
-        // (a tile's top row belongs to the edge rows above, except image row 0)
-        if (t / n_edge_cols < NT && y < H && x < W && (y % CT_H != 0 || y == 0))
-            merge_pixel(dec, L, x, y, z, H, W);
+    const int z = blockIdx.y;
+    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t row_px = (int64_t)n_edge_rows * W;
+    if (idx < row_px) {
+        const int k = (int)(idx / W);
+        merge_pixel(dec, L, (int)(idx - (int64_t)k * W), (k + 1) * CT_H, z, H, W);
+        return;
     }
+    const int64_t j = idx - row_px;
+    if (j >= (int64_t)n_edge_cols * H) return;
+    const int col = (int)(j % n_edge_cols), y = (int)(j / n_edge_cols);
+    const int x = (col >> 1) * CT_W + (col & 1 ? CT_W - 1 : 0);
+    // (a tile's top row belongs to the edge rows above, except image row 0)
+    if (x < W && (y % CT_H != 0 || y == 0)) merge_pixel(dec, L, x, y, z, H, W);
 }
 
 // 26-connectivity: links to the nine neighbours in the plane below
@@ -1134,15 +1136,10 @@ extern "C" int mf_label_components(const int16_t *decoded, int Z, int H, int W, 
     hipLaunchKernelGGL(ccl_tile, dim3((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)Z), dim3(NT), 0,
                        s, decoded, labels, H, W);
     {
-        // edge rows: one block row per tile edge, W threads; edge columns:
-        // 2 per tile column, slabs of NT image rows
         const int n_edge_rows = tiles_y - 1, n_edge_cols = 2 * tiles_x;
-        const int slabs = (H + NT - 1) / NT;
-        const int need_x = W > NT * n_edge_cols ? W : NT * n_edge_cols;
-        hipLaunchKernelGGL(ccl_border,
-                           dim3((unsigned)((need_x + NT - 1) / NT), (unsigned)(n_edge_rows + slabs),
-                                (unsigned)Z),
-                           dim3(NT), 0, s, decoded, labels, H, W, n_edge_rows, n_edge_cols);
+        const int64_t items = (int64_t)n_edge_rows * W + (int64_t)n_edge_cols * H;
+        hipLaunchKernelGGL(ccl_border, dim3((unsigned)((items + NT - 1) / NT), (unsigned)Z), dim3(NT), 0, s,
+                           decoded, labels, H, W, n_edge_rows, n_edge_cols);
     }
     if (conn3d && Z > 1)
         hipLaunchKernelGGL(ccl_merge_z,
