@@ -461,14 +461,27 @@ emit_assigned(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, in
               uint32_t *__restrict__ keys)
 {
     const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
-    const unsigned f = assigned_flags(dec, i0, n);
+    // a pixel is assigned iff its label is >= 0 (mf_label_components): the four
+    // labels come as one 16-byte load and the barcodes need not be read again
+    int lab[4] = {-1, -1, -1, -1};
+    if (i0 + 3 < n) {
+        const int4 v = *reinterpret_cast<const int4 *>(L + i0);
+        lab[0] = v.x; lab[1] = v.y; lab[2] = v.z; lab[3] = v.w;
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < n) lab[k] = L[i0 + k];
+    }
+    (void)dec;
+    unsigned f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f |= (unsigned)(lab[k] >= 0) << k;
     int pos = offsets[blockIdx.x] + block_exclusive_scan(__popc(f));
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (f >> k & 1u) {
             if (pos < cap) {           // cap: the caller's n_pixels sized the lists
                 pix[pos] = (int32_t)(i0 + k);
-                keys[pos] = (uint32_t)L[i0 + k];
+                keys[pos] = (uint32_t)lab[k];
             }
             ++pos;
         }
@@ -1186,6 +1199,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     if (vol > INT32_MAX || n_pixels > vol) return mf::fail(MF_EINVAL, "bad pixel count");
     if (reinterpret_cast<uintptr_t>(decoded) & 7)
         return mf::fail(MF_EINVAL, "decoded must be 8-byte aligned");
+    if (reinterpret_cast<uintptr_t>(labels) & 15)
+        return mf::fail(MF_EINVAL, "labels must be 16-byte aligned");
     Plan pl;
     int rc = make_plan(Z, H, W, n_pixels, n_regions, pl);
     if (rc) return rc;
