@@ -542,18 +542,42 @@ struct StatsArgs {
 // 16 lanes per region.  The region's pixels are taken 16 at a time: every lane
 // fetches one pixel's index, magnitude and distance, works out where its trace
 // lives and parks that in LDS; then all 16 lanes walk the 16 staged pixels in
-// raster order (broadcast LDS reads), lane `sub` accumulating bits sub and
-// sub+16, so the float sums run in the reference's sequential order while the
-// memory latency and the index arithmetic are paid once per 16 pixels.  The
-// scalar statistics are computed redundantly by the 16 lanes and written by
-// lane 0.
+// raster order, lane `sub` accumulating bits sub and sub+16, so the float sums
+// run in the reference's sequential order while the memory latency and the
+// index arithmetic are paid once per 16 pixels.
+//
+// The kernel is bound by VALU issue (float64 instructions hold a SIMD four
+// clocks), so the walk carries as little as it can:
+//  * the two float64 running sums (magnitude, distance) are ONE add per step:
+//    the staged pixel holds {(double)m, d} side by side, even lanes add the
+//    first, odd lanes the second -- each still the sequential sum;
+//  * max magnitude / min distance are order-free: every lane folds its own
+//    pixel and the 16 lanes are reduced once at the end;
+//  * the centroid products (double)coord * (m / sum m) are formed by the lane
+//    that owns the pixel, and lanes 0..2 add z, y, x sequentially (one add
+//    per step instead of three conversions, three products, three adds);
+//  * (tried and dropped: a pixel's 64 bytes of traces as four 16-byte loads
+//    by four lanes, turned through LDS -- 4 instead of 16 load instructions
+//    per chunk: 211 us against 202; processing the regions in root order
+//    instead of emission order: 196.  What is left is a 64-byte-granular
+//    gather of 0.55 GB at 2.7 TB/s.)
+//  * entries past the end of a short chunk hold +0.0, which changes no sum
+//    (the sums start at +0.0, so they are never -0.0), and the walk stops at
+//    the longest chunk of the wave's four groups (a scalar branch).
 constexpr int RSUB = 16;
 
-struct StagePix {          // 32 bytes
-    int64_t toff;          // element offset of the pixel's trace (bit 0)
-    double d;              // distance            | pass 2: weight m / sum(m)
-    float m;               // magnitude
-    int z, y, x;           // pass 2: coordinates
+struct StageGroup {                 // 448 bytes per 16-lane group
+    union {
+        struct {
+            int64_t toff[RSUB];     // element offset of the pixel's trace (bit 0)
+            double val[RSUB][2];    // {(double) magnitude, distance}
+            float m[RSUB];          // magnitude (trace x magnitude statistics)
+        } p1;
+        struct {
+            double prod[RSUB][3];   // z, y, x times m / sum(m)
+            double out[4];          // msum broadcast; centroid hand-over
+        } p2;
+    };
 };
 
 __device__ __forceinline__ void group_sync()
@@ -564,124 +588,175 @@ __device__ __forceinline__ void group_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// longest chunk among the wave's active groups (wave-uniform): the ballot of
+// sub < cnt is a low-bit mask per 16-lane field
+__device__ __forceinline__ int wave_longest(int sub, int cnt)
+{
+    const unsigned long long b = __ballot(sub < cnt);
+    const unsigned f = (unsigned)(b | b >> 16 | b >> 32 | b >> 48) & 0xffffu;
+    return __builtin_amdgcn_readfirstlane(32 - __builtin_clz(f | 1u)) ;
+}
+
 // WIDE: more than 16 bits per codeword (a lane then also carries bit sub + 16)
-template <bool WIDE>
+// TM:   also the mean / min of trace x magnitude (OptimizeIteration)
+template <bool WIDE, bool TM>
 __global__ void __launch_bounds__(NT)
 region_stats(const StatsArgs a)
 {
-    __shared__ StagePix stage[NT / RSUB][RSUB];
+    __shared__ StageGroup stage[NT / RSUB];
     int64_t r = ((int64_t)blockIdx.x * NT + threadIdx.x) / RSUB;
     const int sub = threadIdx.x & (RSUB - 1);
-    StagePix *st = stage[threadIdx.x / RSUB];
+    StageGroup &st = stage[threadIdx.x / RSUB];
     const bool valid = r < a.n_reg;
     if (!valid) r = a.n_reg - 1;          // keep whole groups alive
     const int64_t sp_ = a.span[r];
-    const int64_t i0 = sp_ & 0xffffffffll, i1 = sp_ >> 32;
-    const int n = (int)(i1 - i0);
+    const int i0 = (int)(sp_ & 0xffffffffll), i1 = (int)(sp_ >> 32);
+    const int n = i1 - i0;
     const int plane = a.H * a.W;
     const int first = a.pix[i0];
     const int zfirst = first / plane;
-    const bool want_tm = a.mean_tm || a.min_tm;
 
     // pass 1: magnitude sum / max, distance sum / min; per-bit sums
-    double msum = 0.0, dsum = 0.0, dmin = INFINITY;
+    double acc = 0.0;                     // even lanes: sum m, odd lanes: sum d
+    double dmin = INFINITY;
     float mmax = -INFINITY;
     float s0 = 0.0f, stm0 = 0.0f, mn0 = INFINITY;     // bit sub
     float s1 = 0.0f, stm1 = 0.0f, mn1 = INFINITY;     // bit sub + 16
     const bool has0 = sub < a.B, has1 = WIDE && sub + RSUB < a.B;
     const int64_t boff0 = (int64_t)sub * a.tr_b, boff1 = (int64_t)(sub + RSUB) * a.tr_b;
-    int myp = first;
-    float mym = 0.0f;
-    // this lane's pixel of the next chunk is fetched one chunk ahead
-    int nxp = i0 + sub < i1 ? a.pix[i0 + sub] : first;
-    for (int64_t base = i0; base < i1; base += RSUB) {
-        const int cnt = (int)min((int64_t)RSUB, i1 - base);
-        const int curp = nxp;
-        if (base + RSUB + sub < i1) nxp = a.pix[base + RSUB + sub];
+    const int par = sub & 1;
+    // The dependent loads run ahead of the walk: a chunk's pixel index is
+    // fetched two chunks early and its magnitude and distance one chunk early
+    // (beside the previous chunk's trace loads); the first two chunks'
+    // (pixel, magnitude) stay in registers for the centroid pass.
+    auto load_dist = [&](int p) -> double {
+        return a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[p]
+                          : (double)reinterpret_cast<const float *>(a.dist)[p];
+    };
+    int p0 = first, p1 = first;
+    float m0 = 0.0f, m1 = 0.0f;
+    int pixA = i0 + sub < i1 ? a.pix[i0 + sub] : first;                    // chunk 0
+    int pixB = i0 + RSUB + sub < i1 ? a.pix[i0 + RSUB + sub] : first;      // chunk 1
+    float magA = a.mag[pixA];
+    double distA = load_dist(pixA);
+    int chunk = 0;
+    for (int base = i0; base < i1; base += RSUB, ++chunk) {
+        const int cnt = min(RSUB, i1 - base);
+        const int kmax = wave_longest(sub, cnt);
+        const int curp = pixA;
+        const float curm = magA;
+        const double curd = distA;
+        if (base + RSUB + sub < i1) {          // the next chunk's pixel is known by now
+            pixA = pixB;
+            magA = a.mag[pixA];
+            distA = load_dist(pixA);
+        }
+        if (base + 2 * RSUB + sub < i1) pixB = a.pix[base + 2 * RSUB + sub];
+        if (chunk == 0) { p0 = curp; m0 = curm; }
+        else if (chunk == 1) { p1 = curp; m1 = curm; }
         if (sub < cnt) {
-            myp = curp;
-            mym = a.mag[myp];
-            const double myd = a.dist_f64 ? reinterpret_cast<const double *>(a.dist)[myp]
-                                          : (double)reinterpret_cast<const float *>(a.dist)[myp];
             // a 2-D region lies in one plane; only 3-D needs the division
-            const int zz = a.conn3d ? myp / plane : zfirst;
-            StagePix sp;
-            sp.toff = (int64_t)zz * a.tr_z + (int64_t)(myp - zz * plane) * a.tr_p;
-            sp.d = myd;
-            sp.m = mym;
-            sp.z = sp.y = sp.x = 0;
-            st[sub] = sp;
+            const int zz = a.conn3d ? curp / plane : zfirst;
+            st.p1.toff[sub] = (int64_t)zz * a.tr_z + (int64_t)(curp - zz * plane) * a.tr_p;
+            st.p1.val[sub][0] = (double)curm;
+            st.p1.val[sub][1] = curd;
+            if constexpr (TM) st.p1.m[sub] = curm;
+            mmax = fmaxf(mmax, curm);
+            dmin = fmin(dmin, curd);
+        } else {
+            st.p1.val[sub][0] = 0.0;
+            st.p1.val[sub][1] = 0.0;
         }
         group_sync();
         // issue this lane's trace loads for the whole chunk first
         float t0[RSUB], t1[RSUB];
 #pragma unroll
         for (int k = 0; k < RSUB; ++k) {
-            const int64_t off = st[k < cnt ? k : 0].toff;
-            t0[k] = has0 && k < cnt ? a.traces[off + boff0] : 0.0f;
-            t1[k] = WIDE && has1 && k < cnt ? a.traces[off + boff1] : 0.0f;
+            t0[k] = 0.0f;
+            t1[k] = 0.0f;
+            if (k < kmax) {                                   // scalar branch
+                if (k < cnt) {
+                    const int64_t off = st.p1.toff[k];
+                    if (has0) t0[k] = a.traces[off + boff0];
+                    if constexpr (WIDE) if (has1) t1[k] = a.traces[off + boff1];
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < RSUB; ++k) {
-            if (k < cnt) {
-                const float m = st[k].m;
-                const double d = st[k].d;
-                msum += (double)m;
-                mmax = fmaxf(mmax, m);
-                dsum += d;
-                dmin = fmin(dmin, d);
+            if (k < kmax) {                                   // scalar branch
+                acc += st.p1.val[k][par];
                 s0 = s0 + t0[k];
                 if constexpr (WIDE) s1 = s1 + t1[k];
-                if (want_tm) {
+                if constexpr (TM) {
+                    const float m = st.p1.m[k < cnt ? k : 0];
                     const float tm0 = t0[k] * m;
-                    stm0 = stm0 + tm0; mn0 = fminf(mn0, tm0);
+                    stm0 = stm0 + tm0;
+                    mn0 = fminf(mn0, k < cnt ? tm0 : INFINITY);
                     if constexpr (WIDE) {
                         const float tm1 = t1[k] * m;
-                        stm1 = stm1 + tm1; mn1 = fminf(mn1, tm1);
+                        stm1 = stm1 + tm1;
+                        mn1 = fminf(mn1, k < cnt ? tm1 : INFINITY);
                     }
                 }
             }
         }
         group_sync();      // the next chunk (or pass 2) overwrites the stage
     }
-    // pass 2: magnitude-weighted centroid
-    double cz, cy, cx;
+    // fold the order-free extremes over the group's 16 lanes
+#pragma unroll
+    for (int d = 1; d < RSUB; d <<= 1) {
+        mmax = fmaxf(mmax, __shfl_xor(mmax, d, RSUB));
+        dmin = fmin(dmin, __shfl_xor(dmin, d, RSUB));
+    }
+    // sum m sits in the even lanes, sum d in the odd ones
+    if (sub < 2) st.p2.out[sub] = acc;
+    group_sync();
+    const double msum = st.p2.out[0], dsum = st.p2.out[1];
+    group_sync();
+
+    // pass 2: magnitude-weighted centroid, lanes 0..2 = z, y, x
+    double cacc = 0.0;
+    const int csel = min(sub, 2);
+    chunk = 0;
+    for (int base = i0; base < i1; base += RSUB, ++chunk) {
+        const int cnt = min(RSUB, i1 - base);
+        const int kmax = wave_longest(sub, cnt);
+        if (sub < cnt) {
+            int myp;
+            float mym;
+            if (chunk == 0) { myp = p0; mym = m0; }
+            else if (chunk == 1) { myp = p1; mym = m1; }
+            else {                     // beyond 32 pixels: fetched again
+                myp = a.pix[base + sub];
+                mym = a.mag[myp];
+            }
+            const int zz = a.conn3d ? myp / plane : zfirst;
+            const int rem = myp - zz * plane;
+            const int y = rem / a.W;
+            const int x = rem - y * a.W;
+            const double w = (double)mym / msum;
+            st.p2.prod[sub][0] = (double)zz * w;
+            st.p2.prod[sub][1] = (double)y * w;
+            st.p2.prod[sub][2] = (double)x * w;
+        } else {
+            st.p2.prod[sub][0] = 0.0;
+            st.p2.prod[sub][1] = 0.0;
+            st.p2.prod[sub][2] = 0.0;
+        }
+        group_sync();
+#pragma unroll
+        for (int k = 0; k < RSUB; ++k)
+            if (k < kmax) cacc += st.p2.prod[k][csel];        // scalar branch
+        group_sync();
+    }
+    if (sub < 3) st.p2.out[sub] = cacc;
+    group_sync();
+    if (!valid) return;
+    double cz = st.p2.out[0], cy = st.p2.out[1], cx = st.p2.out[2];
     if (n == 1) {
         cz = zfirst; cy = (first % plane) / a.W; cx = first % a.W;
-    } else {
-        cz = cy = cx = 0.0;
-        for (int64_t base = i0; base < i1; base += RSUB) {
-            const int cnt = (int)min((int64_t)RSUB, i1 - base);
-            if (sub < cnt) {
-                if (n > RSUB) {            // else still in registers from pass 1
-                    myp = a.pix[base + sub];
-                    mym = a.mag[myp];
-                }
-                const int zz = a.conn3d ? myp / plane : zfirst;
-                const int rem = myp - zz * plane;
-                StagePix sp;
-                sp.toff = 0;
-                sp.d = (double)mym / msum;
-                sp.m = mym;
-                sp.z = zz;
-                sp.y = rem / a.W;
-                sp.x = rem - sp.y * a.W;
-                st[sub] = sp;
-            }
-            group_sync();
-#pragma unroll
-            for (int k = 0; k < RSUB; ++k) {
-                if (k < cnt) {
-                    const double w = st[k].d;
-                    cz += (double)st[k].z * w;
-                    cy += (double)st[k].y * w;
-                    cx += (double)st[k].x * w;
-                }
-            }
-            group_sync();
-        }
     }
-    if (!valid) return;
     double mean_int = msum / n, mean_d = n > 1 ? dsum / n : dsum;
     if (a.conn3d) mean_int = (double)(float)mean_int;        // regionprops: f32
     if (a.conn3d && !a.dist_f64) mean_d = (double)(float)mean_d;
@@ -706,13 +781,17 @@ region_stats(const StatsArgs a)
     // (np.mean(list of f32 rows, axis 0), decoding.py:197, 220, 330)
     if (has0) {
         a.inten[r * a.B + sub] = n > 1 ? s0 / (float)n : s0;
-        if (a.mean_tm) a.mean_tm[r * a.B + sub] = stm0 / (float)n;
-        if (a.min_tm) a.min_tm[r * a.B + sub] = mn0;
+        if constexpr (TM) {
+            if (a.mean_tm) a.mean_tm[r * a.B + sub] = stm0 / (float)n;
+            if (a.min_tm) a.min_tm[r * a.B + sub] = mn0;
+        }
     }
     if (has1) {
         a.inten[r * a.B + sub + RSUB] = n > 1 ? s1 / (float)n : s1;
-        if (a.mean_tm) a.mean_tm[r * a.B + sub + RSUB] = stm1 / (float)n;
-        if (a.min_tm) a.min_tm[r * a.B + sub + RSUB] = mn1;
+        if constexpr (TM) {
+            if (a.mean_tm) a.mean_tm[r * a.B + sub + RSUB] = stm1 / (float)n;
+            if (a.min_tm) a.min_tm[r * a.B + sub + RSUB] = mn1;
+        }
     }
 }
 
@@ -1259,10 +1338,14 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     a.B = B; a.Z = Z; a.H = H; a.W = W; a.conn3d = conn3d;
     a.rec = rec; a.inten = inten; a.mean_tm = mean_tm; a.min_tm = min_tm;
     const unsigned gr = (unsigned)((n_regions * RSUB + NT - 1) / NT);
-    if (B > RSUB)
-        hipLaunchKernelGGL(region_stats<true>, dim3(gr), dim3(NT), 0, s, a);
-    else
-        hipLaunchKernelGGL(region_stats<false>, dim3(gr), dim3(NT), 0, s, a);
+    const bool tm = mean_tm || min_tm;
+    if (B > RSUB) {
+        if (tm) hipLaunchKernelGGL((region_stats<true, true>), dim3(gr), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((region_stats<true, false>), dim3(gr), dim3(NT), 0, s, a);
+    } else {
+        if (tm) hipLaunchKernelGGL((region_stats<false, true>), dim3(gr), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((region_stats<false, false>), dim3(gr), dim3(NT), 0, s, a);
+    }
     MF_HIP_CHECK(hipGetLastError());
     return MF_OK;
 }
