@@ -132,7 +132,8 @@ int mf_decode_pixels(const void *image, int image_dtype,
  * on its own) or 26-neighbours (conn3d = 1).
  *
  *   labels  int32 [Z,H,W]: linear index (z*H*W + y*W + x) of the first pixel
- *           of the component in raster order; -1 for unassigned pixels
+ *           of the component in raster order; -1 for unassigned pixels;
+ *           16-byte aligned
  *   counts  int64 [MF_LABEL_COUNTS_LEN] (device): counts[0] = assigned pixels,
  *           counts[1] = components; the caller reads these two back to size
  *           the tables below.  The rest is scratch: the workgroups add their
@@ -166,7 +167,10 @@ int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
  *   mean_tm  f32 [n_regions, B]  per-bit mean of trace*magnitude, or NULL
  *   min_tm   f32 [n_regions, B]  per-bit min  of trace*magnitude, or NULL
  *            (extract_refactors / _extract_backgrounds inputs; 2-D mode)
- *   n_pixels / n_regions: the counts mf_label_components produced. */
+ *   n_pixels / n_regions: the counts mf_label_components produced.
+ *   decoded must be 8-byte and labels 16-byte aligned (MF_EINVAL otherwise;
+ *   any hipMalloc'ed or torch tensor base is): the compaction reads four
+ *   barcodes / four labels per access. */
 int mf_region_table(const int16_t *decoded, const float *magnitudes,
                     const void *distances, int dist_dtype,
                     const float *traces, int64_t tr_z_stride,
