@@ -92,3 +92,20 @@ def test_label_components_against_scipy(gpu_device, conn3d):
         assert np.array_equal(got, exp), (name, conn3d)
         assert counts[0] == (dec >= 0).sum(), name
         assert counts[1] == n_comp, name
+
+
+def test_misaligned_labels_are_rejected(gpu_device):
+    """labels are read and written 16 bytes at a time: a pointer that is not
+    16-byte aligned is an argument error, not a fault."""
+    import torch
+    from merlin_amd import _lib
+    L = _lib.lib()
+    d = torch.zeros((1, 32, 64), dtype=torch.int16, device=gpu_device)
+    buf = torch.empty(32 * 64 + 4, dtype=torch.int32, device=gpu_device)
+    counts = torch.zeros(_lib.MF_LABEL_COUNTS_LEN, dtype=torch.int64,
+                         device=gpu_device)
+    rc = L.mf_label_components(d.data_ptr(), 1, 32, 64, 0,
+                               buf.data_ptr() + 4, counts.data_ptr(),
+                               torch.cuda.current_stream(gpu_device).cuda_stream)
+    assert rc == -1                                   # MF_EINVAL
+    assert b'aligned' in L.mf_last_error_string()
