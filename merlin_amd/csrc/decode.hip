@@ -104,6 +104,14 @@ struct DecodeArgs {
     int chunk;        // codewords per LDS chunk (multiple of 32)
 };
 
+// a uniform value the compiler must take as new at this point: keeps it from
+// hoisting one lane mask per use out of the tile loop (and spilling them)
+__device__ __forceinline__ int opaque_s(int v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 __device__ __forceinline__ int reflect101(int i, int n)
 {
     if (i < 0) i = -i;
@@ -184,6 +192,14 @@ __device__ __forceinline__ f32x2 div_by_recip2(f32x2 n, f32x2 d, f32x2 r)
     return q;
 }
 
+#ifndef MF_OPAQUE_B
+#define MF_OPAQUE_B 1
+#endif
+#if MF_OPAQUE_B
+#define MF_OPQ(v) opaque_s(v)
+#else
+#define MF_OPQ(v) (v)
+#endif
 // A/B switches of dev/mkvariant.sh (all on by default)
 #ifndef MF_PK_F32
 #define MF_PK_F32 1
@@ -252,10 +268,14 @@ constexpr bool tiles_in_sequence(int maxb) { return maxb <= 16 ? MF_SEQ16 : MF_S
 template <int MAXB>
 __device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask, double v, int B)
 {
+    // bits >= B: x is 0 there (the vertical pass writes 0) and so is the mask
+    // bit, so they add +0.0 to a non-negative sum -- no guard, which would cost
+    // one lane mask per bit in (spilled) scalar registers
+    (void)B;
     double d2 = 0.0;
 #pragma unroll
     for (int b = 0; b < MAXB; ++b)
-        if (b < B) {
+        {
 #if MF_D2_FMA
             // x - c with c = v * bit (bit is 0 or 1, so the product is exact
             // and the fused result is the rounded difference)
@@ -498,11 +518,11 @@ decode_kernel(const DecodeArgs a)
         prefetch(0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g * GROUP < B) {
+            if (g * GROUP < MF_OPQ(B)) {
                 hpass(g);
                 __syncthreads();
                 const HT *hs = hs0 + (g % HS_BUFFERS) * (GROUP * RH * TW);
-                if (g + 1 < NG && (g + 1) * GROUP < B) prefetch(g + 1);
+                if (g + 1 < NG && (g + 1) * GROUP < MF_OPQ(B)) prefetch(g + 1);
                 // ---- vertical pass for this thread's PPT pixels ----
 #pragma unroll
                 for (int i = 0; i < GROUP; ++i) {
@@ -554,8 +574,8 @@ decode_kernel(const DecodeArgs a)
                         if constexpr (MF_PK_F32 && PPT % 2 == 0)
                             x[o][b] = v;
                         else
-                            x[o][b] = b >= B ? 0.0f : fast_div ? div_by_recip(v - bgb, sfb, rsb)
-                                                                : (v - bgb) / sfb;
+                            x[o][b] = b >= MF_OPQ(B) ? 0.0f : fast_div ? div_by_recip(v - bgb, sfb, rsb)
+                                                                        : (v - bgb) / sfb;
                     }
                     if constexpr (MF_PK_F32 && PPT % 2 == 0) {
                         // pixel rows in pairs: one packed instruction per two quotients
@@ -567,8 +587,9 @@ decode_kernel(const DecodeArgs a)
                                 n = div_by_recip2(n, (f32x2){sfb, sfb}, (f32x2){rsb, rsb});
                             else
                                 n = n / (f32x2){sfb, sfb};
-                            x[o][b] = b >= B ? 0.0f : n.x;
-                            x[o + 1][b] = b >= B ? 0.0f : n.y;
+                            const bool off = b >= MF_OPQ(B);
+                            x[o][b] = off ? 0.0f : n.x;
+                            x[o + 1][b] = off ? 0.0f : n.y;
                         }
                     }
                     MF_FENCE();
@@ -865,17 +886,24 @@ decode_kernel(const DecodeArgs a)
                 else reinterpret_cast<float *>(a.dist)[pix] = (float)d;
                 if (a.traces && (!a.tr_decoded_only || code >= 0)) {
                     float *tp = a.traces + (int64_t)z * a.tr_z + ((int64_t)gy * W + gx) * a.tr_p;
+                    // (B and the bit stride taken as new here: otherwise one lane
+                    // mask and one offset per bit are hoisted out of the tile loop
+                    // and live in spilled scalar registers)
+                    const int Bs = MF_OPQ(B);
                     if (a.tr_vec) {
                         // pixel-major layout: the pixel's B floats are contiguous
 #pragma unroll
                         for (int b = 0; b < MAXB; b += 4)
-                            if (b < B)
+                            if (b < Bs)
                                 *reinterpret_cast<float4 *>(tp + b) =
                                     make_float4(x[o][b], x[o][b + 1], x[o][b + 2], x[o][b + 3]);
                     } else {
+                        float *q = tp;
 #pragma unroll
-                        for (int b = 0; b < MAXB; ++b)
-                            if (b < B) tp[(int64_t)b * a.tr_b] = x[o][b];
+                        for (int b = 0; b < MAXB; ++b) {
+                            if (b < Bs) *q = x[o][b];
+                            q += a.tr_b;
+                        }
                     }
                 }
             }
