@@ -340,8 +340,19 @@ decode_kernel(const DecodeArgs a)
         for (int i = tid; i < cn * MAXB * 2 / 16; i += NTHREADS) dst[i] = src[i];
         const float *sv = reinterpret_cast<const float *>(a.cbt + a.off_v) + c0;
         const float *sh = reinterpret_cast<const float *>(a.cbt + a.off_hn) + c0;
-        for (int i = tid; i < cn; i += NTHREADS) { lds_v[i] = sv[i]; lds_hn[i] = sh[i]; }
+        if constexpr (UNI) {
+            // a uniform codebook needs neither table in the search; the slot
+            // of lds_hn holds the on-bit masks for the exact distance instead
+            // (used when the whole codebook is resident: single_chunk)
+            uint32_t *lm = reinterpret_cast<uint32_t *>(lds_hn);
+            for (int i = tid; i < cn; i += NTHREADS) lm[i] = g_mask[c0 + i];
+        } else {
+            for (int i = tid; i < cn; i += NTHREADS) { lds_v[i] = sv[i]; lds_hn[i] = sh[i]; }
+        }
     };
+    // uniform codebook: every codeword carries the same value
+    const double v64u = UNI ? g_v64[0] : 0.0;
+    const uint32_t *lds_mask = reinterpret_cast<const uint32_t *>(lds_hn);
     if (single_chunk) load_chunk(0, a.Npad);   // made visible by the first barrier
     // per-bit constants live in LDS, not in 64 scalar registers
     if (tid < MAXB) {
@@ -852,7 +863,19 @@ decode_kernel(const DecodeArgs a)
 #ifdef MF_ABL_NOF64
             double d2 = (double)best;
 #else
-            double d2 = exact_d2<MAXB>(x[o], g_mask[win], g_v64[win], B);
+            // the winner's mask and value: from LDS / a scalar for a resident
+            // uniform codebook (no dependent global gather in front of the
+            // stores), else from the table in global memory
+            uint32_t wmask;
+            double wv;
+            if (UNI && single_chunk) {
+                wmask = lds_mask[win];
+                wv = v64u;
+            } else {
+                wmask = g_mask[win];
+                wv = g_v64[win];
+            }
+            double d2 = exact_d2<MAXB>(x[o], wmask, wv, B);
 #endif
             // a zero padding row can only "win" when every real sum is <= 0
 #ifdef MF_ABL_NOSCAN
