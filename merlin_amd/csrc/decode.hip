@@ -585,8 +585,10 @@ decode_kernel(const DecodeArgs a)
                         if constexpr (MF_PK_F32 && PPT % 2 == 0)
                             x[o][b] = v;
                         else
-                            x[o][b] = b >= MF_OPQ(B) ? 0.0f : fast_div ? div_by_recip(v - bgb, sfb, rsb)
-                                                                        : (v - bgb) / sfb;
+                            // bits >= B need no guard: their windows are loaded as
+                            // zeros, their background is 0 and their scale 1 (set
+                            // above), so the quotient is +0.0 by itself
+                            x[o][b] = fast_div ? div_by_recip(v - bgb, sfb, rsb) : (v - bgb) / sfb;
                     }
                     if constexpr (MF_PK_F32 && PPT % 2 == 0) {
                         // pixel rows in pairs: one packed instruction per two quotients
@@ -598,9 +600,8 @@ decode_kernel(const DecodeArgs a)
                                 n = div_by_recip2(n, (f32x2){sfb, sfb}, (f32x2){rsb, rsb});
                             else
                                 n = n / (f32x2){sfb, sfb};
-                            const bool off = b >= MF_OPQ(B);
-                            x[o][b] = off ? 0.0f : n.x;
-                            x[o + 1][b] = off ? 0.0f : n.y;
+                            x[o][b] = n.x;              // bits >= B: +0.0 by itself, see above
+                            x[o + 1][b] = n.y;
                         }
                     }
                     MF_FENCE();
