@@ -314,9 +314,11 @@ decode_kernel(const DecodeArgs a)
     unsigned char *lds_a = smem + HS_BYTES;                          // bf16 [chunk][MAXB]
     float *lds_v = reinterpret_cast<float *>(lds_a + (size_t)a.chunk * MAXB * 2);
     float *lds_hn = lds_v + a.chunk;
-    float *lds_sf = lds_hn + a.chunk;                                // [MAXB] scale factors
-    float *lds_bg = lds_sf + MAXB;                                   // [MAXB] backgrounds
-    float *lds_rs = lds_bg + MAXB;                                   // [MAXB] RN(1 / scale)
+    // per-bit constants, each stored twice side by side: one 8-byte read puts
+    // them where the packed two-row arithmetic wants them (no register moves)
+    f32x2 *lds_sf = reinterpret_cast<f32x2 *>(lds_hn + a.chunk);     // [MAXB] scale factors
+    f32x2 *lds_bg = lds_sf + MAXB;                                   // [MAXB] backgrounds
+    f32x2 *lds_rs = lds_bg + MAXB;                                   // [MAXB] RN(1 / scale)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -356,9 +358,12 @@ decode_kernel(const DecodeArgs a)
     if (single_chunk) load_chunk(0, a.Npad);   // made visible by the first barrier
     // per-bit constants live in LDS, not in 64 scalar registers
     if (tid < MAXB) {
-        lds_sf[tid] = tid < B ? a.sf[tid] : 1.0f;
-        lds_bg[tid] = tid < B ? a.bg[tid] : 0.0f;
-        lds_rs[tid] = tid < B ? 1.0f / a.sf[tid] : 1.0f;     // IEEE division
+        const float sfv = tid < B ? a.sf[tid] : 1.0f;
+        const float bgv = tid < B ? a.bg[tid] : 0.0f;
+        const float rsv = tid < B ? 1.0f / a.sf[tid] : 1.0f;     // IEEE division
+        lds_sf[tid] = (f32x2){sfv, sfv};
+        lds_bg[tid] = (f32x2){bgv, bgv};
+        lds_rs[tid] = (f32x2){rsv, rsv};
     }
 
     // XCD-aware tile walk: blocks with the same (blockIdx % 8) share an XCD
@@ -395,7 +400,9 @@ decode_kernel(const DecodeArgs a)
         uint32_t win[NTASK][WDW];
         double kd[2 * R + 1];
 #pragma unroll
-        for (int j = 0; j <= 2 * R; ++j) kd[j] = (double)a.kfix[j];
+        // taps times 2^-32 (exact): the vertical sum then comes out as
+        // V * 2^-32 + 0.5 without a scaling step of its own
+        for (int j = 0; j <= 2 * R; ++j) kd[j] = (double)a.kfix[j] * 0x1p-32;
 
         // ---- global -> register windows for one group of bits ----
         // Interior tiles: the task's window sits at a tile-invariant byte
@@ -538,7 +545,8 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                 for (int i = 0; i < GROUP; ++i) {
                     const int b = g * GROUP + i;
-                    const float sfb = lds_sf[b], bgb = lds_bg[b], rsb = lds_rs[b];
+                    const f32x2 sf2 = lds_sf[b], bg2 = lds_bg[b], rs2 = lds_rs[b];
+                    const float sfb = sf2.x, bgb = bg2.x, rsb = rs2.x;
                     HT col[PPT + 2 * R];
 #pragma unroll
                     for (int j = 0; j < PPT + 2 * R; ++j)
@@ -556,11 +564,14 @@ decode_kernel(const DecodeArgs a)
                             // pair sums < 2^33, taps < 2^16); V * 2^-32 + 0.5 is exact
                             // too (an integer multiple of 2^-32 below 2^17), so the
                             // truncating conversion is (V + 2^31) >> 32
-                            double acc = kd[R] * cd[o + R];
+                            // With the taps pre-scaled by 2^-32 and the sum started at
+                            // 0.5, every partial sum is a multiple of 2^-32 below 2^17:
+                            // still exact, one operation less per pixel.
+                            double acc = __builtin_fma(kd[R], cd[o + R], 0.5);
 #pragma unroll
                             for (int j = 1; j <= R; ++j)
                                 acc = __builtin_fma(kd[R + j], cd[o + R - j] + cd[o + R + j], acc);
-                            v = (float)(uint32_t)__builtin_fma(acc, 0x1p-32, 0.5);
+                            v = (float)(uint32_t)acc;
                         } else if constexpr (IS_U16) {
                             // V = sum k_j * H_j needs 48 bits: split H into 16-bit
                             // halves, two exact u32 sums, out = (V + 2^31) >> 32
@@ -595,11 +606,11 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                         for (int o = 0; o < PPT; o += 2) {
                             f32x2 n = {x[o][b], x[o + 1][b]};
-                            n = n - (f32x2){bgb, bgb};
+                            n = n - bg2;
                             if (fast_div)
-                                n = div_by_recip2(n, (f32x2){sfb, sfb}, (f32x2){rsb, rsb});
+                                n = div_by_recip2(n, sf2, rs2);
                             else
-                                n = n / (f32x2){sfb, sfb};
+                                n = n / sf2;
                             x[o][b] = n.x;              // bits >= B: +0.0 by itself, see above
                             x[o + 1][b] = n.y;
                         }
@@ -952,7 +963,7 @@ int launch(DecodeArgs &a, hipStream_t stream)
     // as many workgroups per CU as the register budget allows waves per SIMD
     // (160 KB of LDS shared between them)
     const size_t budget = (size_t)160 * 1024 / (waves_per_simd(MAXB, UNI) * 4 / NWAVES);
-    int chunk = (int)((budget - hs_bytes - 384) / per_word) & ~31;
+    int chunk = (int)((budget - hs_bytes - 768) / per_word) & ~31;
     if (chunk >= a.Npad) {
         chunk = a.Npad;
     } else {
@@ -961,7 +972,7 @@ int launch(DecodeArgs &a, hipStream_t stream)
         chunk = ((a.Npad / 32 + n_chunks - 1) / n_chunks) * 32;
     }
     a.chunk = chunk;
-    size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * sizeof(float);
+    size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * 2 * sizeof(float);
 #ifdef MF_LDS_MIN   // development: fewer workgroups per CU (room for other streams' kernels)
     if (lds < MF_LDS_MIN) lds = MF_LDS_MIN;
 #endif
