@@ -408,17 +408,24 @@ decode_kernel(const DecodeArgs a)
         // Interior tiles: the task's window sits at a tile-invariant byte
         // offset voff[k] (one register per task, worked out before the tile
         // loop) from a base that is uniform over the workgroup.
-        int tid_l = tid;
-        asm volatile("" : "+v"(tid_l));      // keeps the index arithmetic of the
-                                             // border path out of the registers
-                                             // the tile loop carries
         auto prefetch = [&](int g) {
-            const char *gbase = reinterpret_cast<const char *>(img) +
-                                ((int64_t)(g * GROUP) * a.bit_stride + (int64_t)z * a.z_stride +
-                                 (int64_t)(y0 - R) * W + (x0 - RA)) * (int64_t)sizeof(PIX);
+            if (interior) {
+                const char *gbase = reinterpret_cast<const char *>(img) +
+                                    ((int64_t)(g * GROUP) * a.bit_stride + (int64_t)z * a.z_stride +
+                                     (int64_t)(y0 - R) * W + (x0 - RA)) * (int64_t)sizeof(PIX);
+                // every task of the group carries a real bit (the usual case:
+                // B a multiple of the group): plain loads, no lane masks
+                if (TASKS == NTASK * NTHREADS && (FULL || (g + 1) * GROUP <= MF_OPQ(B))) {
 #pragma unroll
-            for (int k = 0; k < NTASK; ++k) {
-                if (interior) {
+                    for (int k = 0; k < NTASK; ++k) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(gbase + voff[k]);
+#pragma unroll
+                        for (int d = 0; d < WDW; ++d) win[k][d] = src[d];
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int k = 0; k < NTASK; ++k) {
                     const bool live = (k + 1 < NTASK || tid + k * NTHREADS < TASKS) &&
                                       (FULL || g * GROUP + (tid + k * NTHREADS) / (RH * 16) < B);
                     if (live) {
@@ -429,8 +436,16 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                         for (int d = 0; d < WDW; ++d) win[k][d] = 0u;
                     }
-                    continue;
                 }
+                return;
+            }
+            // border tiles only.  The thread index is taken as new here so that
+            // the index and reflection arithmetic stays inside this branch (the
+            // compiler otherwise hoists it and runs it for every tile)
+            int tid_l = tid;
+            asm volatile("" : "+v"(tid_l));
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k) {
                 const int q = tid_l + k * NTHREADS;
                 const int bit = g * GROUP + q / (RH * 16);
                 const int rem = q % (RH * 16);
@@ -439,9 +454,6 @@ decode_kernel(const DecodeArgs a)
                     const PIX *plane = img + (int64_t)bit * a.bit_stride + (int64_t)z * a.z_stride;
                     const int gy = y0 - R + row, gx = x0 + 4 * cg - RA;
                     {
-                        // border tiles only: keep the reflection arithmetic inside
-                        // this branch (the compiler otherwise hoists and runs it
-                        // for every tile)
                         int gys = gy, gxs = gx;
                         asm volatile("" : "+v"(gys), "+v"(gxs));
                         const PIX *rowp = plane + (int64_t)reflect101(gys, H) * W;
