@@ -1,0 +1,34 @@
+"""GPU: a fixed sample of the randomised sweep dev/fuzz_fov.py -- Decode.run_fov
+(HIP path) against the oracle over random codebooks (8-32 bits), shapes, blur
+widths, thresholds, crops, minimum areas, 2-D / 3-D labelling and spot
+densities.  Bars as in test_gpu_fov.py: integer columns and record sets equal;
+2-D scalars within 1e-12 and per-bit means bit-exact; 3-D floats within 1e-6.
+The sweep itself (thousands of cases, profiles/r02/fuzz_fov.txt) is run by
+hand; these 40 seeds ride with every GPU run."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _sweep():
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_fov', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_fov.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('block', range(4))
+def test_random_fovs_match_oracle(block, gpu_device):
+    sweep = _sweep()
+    records = 0
+    for seed in range(3000 + 10 * block, 3010 + 10 * block):
+        ok, why, desc, n = sweep.one_case(seed, gpu_device)
+        assert ok, '%s: %s' % (desc, why)
+        records += n
+    assert records > 0
