@@ -55,7 +55,7 @@ def one_case(seed, dev):
     if kind == 0:
         cb = load_golden('g2_synth192')['codebook']
     else:
-        B = int(rng.choice([8, 12, 16, 20, 24, 32]))
+        B = int(rng.choice([8, 10, 12, 14, 16, 18, 20, 22, 24, 27, 32]))
         N = int(rng.integers(3, 300))
         w = int(rng.integers(2, 6))
         from math import comb
