@@ -22,7 +22,7 @@ bgopt = len(sys.argv) > 1 and sys.argv[1] == 'bg'
 
 
 def go(n):
-    it = OptimizeIteration(cb, {'fov_per_iteration': n, 'optimize_background': bgopt},
+    it = OptimizeIteration(cb, {'fov_per_iteration': n, 'optimize_background': bgopt, 'fragment_workers': int(os.environ.get('MF_WORKERS', '4'))},
                            fovs=[0], zCount=bench.Z, initialScaleFactors=sf0,
                            imageProvider=lambda f, z: fov[:, z], device=dev, seed=1).run()
     it.get_scale_factors()
