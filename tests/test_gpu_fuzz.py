@@ -4,7 +4,8 @@ widths, thresholds, crops, minimum areas, 2-D / 3-D labelling and spot
 densities.  Bars as in test_gpu_fov.py: integer columns and record sets equal;
 2-D scalars within 1e-12 and per-bit means bit-exact; 3-D floats within 1e-6.
 The sweep itself (thousands of cases, profiles/r02/fuzz_fov.txt) is run by
-hand; these 40 seeds ride with every GPU run."""
+hand; these 40 seeds (and 60 of the preprocess sweep dev/fuzz_pp.py) ride with
+every GPU run."""
 import importlib.util
 import os
 
@@ -32,3 +33,23 @@ def test_random_fovs_match_oracle(block, gpu_device):
         assert ok, '%s: %s' % (desc, why)
         records += n
     assert records > 0
+
+
+def _pp_sweep():
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_pp', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_pp.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('block', range(2))
+def test_random_preprocess_cases_match_oracle(block, gpu_device):
+    """60 seeds of dev/fuzz_pp.py: high pass bit-exact, Lucy-Richardson
+    bit-exact up to two iterations and within 1e-9 after, uint16 hand-over
+    equal except where the oracle's float64 value is within that 1e-9 of an
+    integer, histogram equal to the histogram of the output."""
+    sweep = _pp_sweep()
+    for seed in range(4000 + 30 * block, 4030 + 30 * block):
+        ok, why, desc = sweep.one_case(seed, gpu_device)
+        assert ok, '%s: %s' % (desc, why)
