@@ -1,4 +1,5 @@
-"""Randomised parity sweep: Decode.run_fov (HIP path) against the oracle over
+"""Randomised parity sweep: Decode.run_fov (HIP path) against the oracle (and the
+typed record sink against the plain frame cast to the database's types) over
 random codebooks, image shapes, blur widths, thresholds, crops, minimum areas,
 2-D / 3-D labelling and spot densities (sparse to merged blobs).  A development
 check, not part of the product: run on the GPU box as
@@ -110,6 +111,23 @@ def one_case(seed, dev):
                 ok, why = False, '2-D scalars beyond 1e-12'
             elif not np.array_equal(r[:, 14:], e[:, 14:]):
                 ok, why = False, '2-D per-bit means not bit-exact'
+    if ok:
+        # the typed record sink (barcode database column types, written on the
+        # device) must hold exactly the plain frame cast by the database
+        from merlin_amd import barcodedb
+        db = barcodedb.BarcodeDB(ArrayCodebook(cb))
+        typed, _ = task.run_fov(torch.from_numpy(img).to(dev), sf, bg, fov=fov,
+                                globalAligner=aligner, database=db)
+        schema = barcodedb.bc_column_types(B)
+        cast = bc.astype(schema) if len(bc) else bc
+        if len(typed) != len(bc):
+            ok, why = False, 'typed sink: %d rows vs %d' % (len(typed), len(bc))
+        elif len(bc):
+            for c in schema:
+                a, b_ = typed[c].to_numpy(), cast[c].to_numpy()
+                if not np.array_equal(a, b_, equal_nan=a.dtype.kind == 'f'):
+                    ok, why = False, 'typed sink column %s' % c
+                    break
     if not ok:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         np.savez(os.path.join(ROOT, 'gpurun_out', 'fuzz_fail.npz'), cb=cb,
