@@ -53,3 +53,16 @@ def test_random_preprocess_cases_match_oracle(block, gpu_device):
     for seed in range(4000 + 30 * block, 4030 + 30 * block):
         ok, why, desc = sweep.one_case(seed, gpu_device)
         assert ok, '%s: %s' % (desc, why)
+
+
+@pytest.mark.parametrize('block', range(2))
+def test_random_refactor_cases_match_oracle(block, gpu_device):
+    """40 seeds of dev/fuzz_refactors.py: extract_refactors with and without
+    the background term, 1e-12 relative, NaNs in the same places."""
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_refactors', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_refactors.py'))
+    sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sweep)
+    for seed in range(8000 + 20 * block, 8020 + 20 * block):
+        ok, why, desc = sweep.one_case(seed, gpu_device)
+        assert ok, '%s: %s' % (desc, why)
