@@ -66,3 +66,15 @@ def test_random_refactor_cases_match_oracle(block, gpu_device):
     for seed in range(8000 + 20 * block, 8020 + 20 * block):
         ok, why, desc = sweep.one_case(seed, gpu_device)
         assert ok, '%s: %s' % (desc, why)
+
+
+def test_random_label_volumes_match_scipy(gpu_device):
+    """300 seeds of dev/fuzz_ccl.py: mf_label_components against scipy's
+    labelling of every code, both connectivities."""
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_ccl', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_ccl.py'))
+    sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sweep)
+    for seed in range(40000, 40300):
+        ok, why, desc = sweep.one_case(seed, gpu_device)
+        assert ok, '%s: %s' % (desc, why)
