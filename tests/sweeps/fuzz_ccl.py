@@ -2,7 +2,7 @@
 barcode (tests/test_gpu_ccl.py's checker): random volumes, code counts, fill
 fractions (sparse to percolating), blob sizes, both connectivities.  Labels and
 both counts must be equal.
-    python3 -u dev/fuzz_ccl.py [cases] [first_seed]"""
+    python3 -u tests/sweeps/fuzz_ccl.py [cases] [first_seed]"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from scipy import ndimage
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from test_gpu_ccl import _label_gpu, _label_ref       # noqa: E402

@@ -3,7 +3,7 @@ typed record sink against the plain frame cast to the database's types) over
 random codebooks, image shapes, blur widths, thresholds, crops, minimum areas,
 2-D / 3-D labelling and spot densities (sparse to merged blobs).  A development
 check, not part of the product: run on the GPU box as
-    python3 -u dev/fuzz_fov.py [cases] [first_seed]
+    python3 -u tests/sweeps/fuzz_fov.py [cases] [first_seed]
 Stops at the first mismatch and saves its inputs to gpurun_out/fuzz_fail.npz."""
 import os
 import sys
@@ -14,7 +14,7 @@ import numpy as np
 import pandas
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -6,7 +6,7 @@ Bars as in tests/test_gpu_preprocess.py: high pass bit-exact; deconvolution
 bit-exact up to two iterations, 1e-9 relative after; the uint16 hand-over
 (a truncation) off by one count only where the oracle's float64 value is within
 that 1e-9 of an integer.  A development check:
-    python3 -u dev/fuzz_pp.py [cases] [first_seed]"""
+    python3 -u tests/sweeps/fuzz_pp.py [cases] [first_seed]"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import preprocess_oracle as po                     # noqa: E402

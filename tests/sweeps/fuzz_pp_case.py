@@ -1,8 +1,8 @@
-"""Details of one dev/fuzz_pp.py case: python3 dev/fuzz_pp_case.py <seed>"""
+"""Details of one tests/sweeps/fuzz_pp.py case: python3 tests/sweeps/fuzz_pp_case.py <seed>"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'dev'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests', 'sweeps'))
 import preprocess_oracle as po
 from merlin_amd import preprocess as pp
 import fuzz_pp

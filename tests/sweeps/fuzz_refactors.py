@@ -3,7 +3,7 @@ fragment's reduction: region table with trace x magnitude statistics on the
 GPU, ordered per-barcode sums on the host) against the oracle, with and
 without the background term, over random codebooks, planes, area thresholds.
 Bar: 1e-12 relative, NaNs in the same places (tests/test_gpu_parity.py).
-    python3 -u dev/fuzz_refactors.py [cases] [first_seed]"""
+    python3 -u tests/sweeps/fuzz_refactors.py [cases] [first_seed]"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))

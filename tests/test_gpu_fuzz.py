@@ -1,10 +1,10 @@
-"""GPU: a fixed sample of the randomised sweep dev/fuzz_fov.py -- Decode.run_fov
+"""GPU: a fixed sample of the randomised sweep tests/sweeps/fuzz_fov.py -- Decode.run_fov
 (HIP path) against the oracle over random codebooks (8-32 bits), shapes, blur
 widths, thresholds, crops, minimum areas, 2-D / 3-D labelling and spot
 densities.  Bars as in test_gpu_fov.py: integer columns and record sets equal;
 2-D scalars within 1e-12 and per-bit means bit-exact; 3-D floats within 1e-6.
 The sweep itself (thousands of cases, profiles/r02/fuzz_fov.txt) is run by
-hand; these 40 seeds (and 60 of the preprocess sweep dev/fuzz_pp.py) ride with
+hand; these 40 seeds (and 60 of the preprocess sweep tests/sweeps/fuzz_pp.py) ride with
 every GPU run."""
 import importlib.util
 import os
@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 def _sweep():
     spec = importlib.util.spec_from_file_location(
-        'fuzz_fov', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_fov.py'))
+        'fuzz_fov', os.path.join(_HERE, 'sweeps', 'fuzz_fov.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -37,7 +37,7 @@ def test_random_fovs_match_oracle(block, gpu_device):
 
 def _pp_sweep():
     spec = importlib.util.spec_from_file_location(
-        'fuzz_pp', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_pp.py'))
+        'fuzz_pp', os.path.join(_HERE, 'sweeps', 'fuzz_pp.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -45,7 +45,7 @@ def _pp_sweep():
 
 @pytest.mark.parametrize('block', range(2))
 def test_random_preprocess_cases_match_oracle(block, gpu_device):
-    """60 seeds of dev/fuzz_pp.py: high pass bit-exact, Lucy-Richardson
+    """60 seeds of tests/sweeps/fuzz_pp.py: high pass bit-exact, Lucy-Richardson
     bit-exact up to two iterations and within 1e-9 after, uint16 hand-over
     equal except where the oracle's float64 value is within that 1e-9 of an
     integer, histogram equal to the histogram of the output."""
@@ -57,10 +57,10 @@ def test_random_preprocess_cases_match_oracle(block, gpu_device):
 
 @pytest.mark.parametrize('block', range(2))
 def test_random_refactor_cases_match_oracle(block, gpu_device):
-    """40 seeds of dev/fuzz_refactors.py: extract_refactors with and without
+    """40 seeds of tests/sweeps/fuzz_refactors.py: extract_refactors with and without
     the background term, 1e-12 relative, NaNs in the same places."""
     spec = importlib.util.spec_from_file_location(
-        'fuzz_refactors', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_refactors.py'))
+        'fuzz_refactors', os.path.join(_HERE, 'sweeps', 'fuzz_refactors.py'))
     sweep = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sweep)
     for seed in range(8000 + 20 * block, 8020 + 20 * block):
@@ -69,10 +69,10 @@ def test_random_refactor_cases_match_oracle(block, gpu_device):
 
 
 def test_random_label_volumes_match_scipy(gpu_device):
-    """300 seeds of dev/fuzz_ccl.py: mf_label_components against scipy's
+    """300 seeds of tests/sweeps/fuzz_ccl.py: mf_label_components against scipy's
     labelling of every code, both connectivities."""
     spec = importlib.util.spec_from_file_location(
-        'fuzz_ccl', os.path.join(os.path.dirname(_HERE), 'dev', 'fuzz_ccl.py'))
+        'fuzz_ccl', os.path.join(_HERE, 'sweeps', 'fuzz_ccl.py'))
     sweep = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sweep)
     for seed in range(40000, 40300):
