@@ -112,7 +112,9 @@ int mf_codebook_prepare(const double *h_codebook, int N, int B, void *table,
  * (lowest index on exact ties) for every pixel that can pass the distance
  * threshold; for a pixel farther than the threshold whose two best float32
  * scores differ by < 1e-5 the reported winner may be either of them, so its
- * distance agrees with the exact one to ~1e-6 relative. */
+ * distance agrees with the exact one to 2^-18 = 4e-6 relative (the search
+ * key carries its accumulator slot in the low four mantissa bits, which moves
+ * a key by < 2^-19 of itself; measured worst case 2.4e-6). */
 int mf_decode_pixels(const void *image, int image_dtype,
                      int B, int Z, int H, int W,
                      int64_t img_bit_stride, int64_t img_z_stride,

@@ -177,7 +177,7 @@ def test_full_size_crops_match_oracle(full):
         got = vol.distances[gs].cpu().numpy()
         clear = (gap[sl] > 1e-4) | hit
         assert np.array_equal(got[clear], d[sl][clear])
-        np.testing.assert_allclose(got, d[sl], rtol=2e-6)
+        np.testing.assert_allclose(got, d[sl], rtol=4e-6)
     assert decoded_any > 20
 
 

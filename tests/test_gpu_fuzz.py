@@ -78,3 +78,17 @@ def test_random_label_volumes_match_scipy(gpu_device):
     for seed in range(40000, 40300):
         ok, why, desc = sweep.one_case(seed, gpu_device)
         assert ok, '%s: %s' % (desc, why)
+
+
+@pytest.mark.parametrize('block', range(2))
+def test_random_decode_pixels_calls_match_oracle(block, gpu_device):
+    """80 seeds of tests/sweeps/fuzz_decode.py: u16 / f32 / f64 images, uniform
+    and mixed-weight codebooks, every blur radius; decoded image, magnitudes,
+    traces bit-exact, distances bit-exact except at far tied pixels (4e-6)."""
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_decode', os.path.join(_HERE, 'sweeps', 'fuzz_decode.py'))
+    sweep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sweep)
+    for seed in range(50000 + 40 * block, 50040 + 40 * block):
+        ok, why, desc = sweep.one_case(seed, gpu_device)
+        assert ok, '%s: %s' % (desc, why)

@@ -61,11 +61,11 @@ def assert_distances(d, od, gap, decoded):
     """Distances are bit-exact wherever the winner is unambiguous (runner-up
     more than 1e-4 away in squared distance, i.e. 5e-5 in score) or the pixel
     decodes; an ambiguous far pixel may report either near-tied codeword, so
-    its distance agrees to float32-score rounding (documented in
-    include/merfish_hip.h)."""
+    its distance agrees to 2^-18 = 4e-6 relative: the slot bits of the search
+    key plus float32-score rounding (documented in include/merfish_hip.h)."""
     clear = (gap > 1e-4) | (decoded >= 0)
     assert np.array_equal(d[clear], od[clear])
-    np.testing.assert_allclose(d[~clear], od[~clear], rtol=2e-6, atol=0)
+    np.testing.assert_allclose(d[~clear], od[~clear], rtol=4e-6, atol=0)
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -293,7 +293,7 @@ def test_exclusive_codebook_path_matches_runner_up_path(gpu_device):
     """MHD4 codebook + threshold <= 0.5176: the kernel drops the runner-up
     (no two codewords can both be within reach, decode.hip codebook_exclusive).
     Same decoded image and magnitudes as the top-2 path; distances identical
-    wherever a pixel decodes and within the documented 2e-6 elsewhere."""
+    wherever a pixel decodes and within the documented 4e-6 elsewhere."""
     import torch
     from merlin_amd import _lib
     from merlin_amd.decoding import PixelBasedDecoder
@@ -315,7 +315,7 @@ def test_exclusive_codebook_path_matches_runner_up_path(gpu_device):
         assert torch.equal(a.magnitudes, b.magnitudes)
         xa, xb = a.distances.cpu().numpy(), b.distances.cpu().numpy()
         assert np.array_equal(xa[da >= 0], xb[da >= 0])
-        np.testing.assert_allclose(xa, xb, rtol=2e-6, atol=0)
+        np.testing.assert_allclose(xa, xb, rtol=4e-6, atol=0)
 
 
 @pytest.mark.parametrize('spots', [0, 3])
