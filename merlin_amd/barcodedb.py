@@ -57,7 +57,16 @@ class TypedBarcodes(object):
                                 .format(name, got.dtype, got.shape,
                                         np.dtype(dt), len(self.index)))
 
-    def to_frame(self) -> pandas.DataFrame:
+    def to_frame(self, copy: bool = False) -> pandas.DataFrame:
+        """The records as a DataFrame.  The columns of a GPU hand-over are
+        views of page-locked staging buffers sized for every region of the
+        FOV, not just the kept rows: ``copy=True`` moves the kept rows into
+        ordinary numpy memory (what a table that outlives the FOV must hold,
+        or pinned memory grows with the FOV count)."""
+        if copy:
+            return pandas.DataFrame(
+                {k: np.array(v) for k, v in self.columns.items()},
+                index=np.array(self.index), copy=False)
         return pandas.DataFrame(self.columns, index=self.index, copy=False)
 
 
@@ -138,7 +147,10 @@ class BarcodeDB(object):
             if fov is None:
                 raise ValueError('typed records are written one FOV at a time')
             barcodeInformation.check(self._get_bc_column_types())
-            self._append_table(int(fov), barcodeInformation.to_frame())
+            # zero-copy only on the way into a Parquet file; a table kept in
+            # memory owns ordinary memory, not the FOV's pinned staging buffers
+            self._append_table(int(fov), barcodeInformation.to_frame(
+                copy=self._dir is None))
             return
         if fov is None:
             for f, rows in barcodeInformation.groupby('fov', sort=False):

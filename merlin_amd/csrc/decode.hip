@@ -1296,6 +1296,20 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     }
     int rc = mf_gaussian_taps(ksize, sigma, a.kfix, a.kflt);
     if (rc) return rc;
+    int Reff = R;
+    if (image_dtype == MF_DTYPE_U16 && R > 0 && a.kfix[R] >= 65536u) {
+        // A very narrow Gaussian (sigma < ~0.21): every side tap rounds to 0 and
+        // the centre tap is exactly 2^16, which does not fit the 16-bit halves
+        // the v_dot2_u32_u16 row pass packs its taps into.  Such a kernel is
+        // the identity on u16 pixels ((p * 2^32 + 2^31) >> 32 = p): run the
+        // single-tap kernel, which carries 65536 as a 24-bit multiplier.
+        Reff = 0;
+        rc = mf_gaussian_taps(1, sigma, a.kfix, a.kflt);
+        if (rc) return rc;
+    }
+    for (int j = 0; j <= 2 * Reff; ++j)
+        if (image_dtype == MF_DTYPE_U16 && Reff > 0 && a.kfix[j] >= 65536u)
+            return mf::fail(MF_EUNSUPPORTED, "fixed-point tap %u does not fit 16 bits", a.kfix[j]);
     a.dthr = distance_threshold;
     a.mthr = magnitude_threshold;
     a.decoded = decoded;
@@ -1310,6 +1324,6 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     a.tr_vec = traces && tr_bit_stride == 1 && !(B & 3) && !(tr_pix_stride & 3) &&
                !(tr_z_stride & 3) && !(reinterpret_cast<uintptr_t>(traces) & 15);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (image_dtype == MF_DTYPE_U16) return dispatch_radius<uint16_t>(R, a, s);
-    return dispatch_radius<float>(R, a, s);
+    if (image_dtype == MF_DTYPE_U16) return dispatch_radius<uint16_t>(Reff, a, s);
+    return dispatch_radius<float>(Reff, a, s);
 }

@@ -1436,7 +1436,14 @@ int run_lr_batch(const WT *wi, int nb, int i0, int H, int W, int R, const Taps &
                         : (void *)(reinterpret_cast<uint16_t *>(out) + (int64_t)i0 * hw);
     // uint16 output, an operand set without special cases (iteration >= 3) and
     // 4-byte aligned pairs: the last iteration writes the hand-over itself
-    const bool fuse_last = pairs && !out_f64 && iterations >= 4 && !(reinterpret_cast<uintptr_t>(dst) & 3);
+    // (not when the output overlaps the observed image: other workgroups of the
+    // last launch still read that image, halo rows included, while this one
+    // writes; the separate hand-over kernel runs after every read instead)
+    const uintptr_t wi_lo = reinterpret_cast<uintptr_t>(wi), wi_hi = wi_lo + (size_t)nb * hw * sizeof(WT);
+    const uintptr_t d_lo = reinterpret_cast<uintptr_t>(dst), d_hi = d_lo + (size_t)nb * hw * sizeof(uint16_t);
+    const bool aliased = d_lo < wi_hi && wi_lo < d_hi;
+    const bool fuse_last = pairs && !out_f64 && iterations >= 4 && !aliased &&
+                           !(reinterpret_cast<uintptr_t>(dst) & 3);
     a.out16 = reinterpret_cast<uint16_t *>(dst);
     a.hist = hist;
     a.hist_group = hist_group > 0 ? hist_group : 1;

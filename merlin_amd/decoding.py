@@ -354,20 +354,30 @@ class PixelBasedDecoder(object):
     _CACHED_VOLUMES = 2       # device volumes kept for the extraction calls
 
     @staticmethod
-    def _content_key(decodedImage, pixelMagnitudes):
-        """Checksum of the two images an in-place edit would touch
-        (``di[pm < t] = -1`` and the like)."""
+    def _content_key(decodedImage, pixelMagnitudes, pixelTraces=None,
+                     distances=None):
+        """Checksum of the images an in-place edit would touch: all of
+        decodedImage and pixelMagnitudes (``di[pm < t] = -1`` and the like) and
+        a strided sample (every 61st element) of the traces and distances --
+        a wholesale rewrite of those is caught, an edit of single trace values
+        is not (documented in INTEGRATION.md)."""
+        parts = [np.ascontiguousarray(decodedImage),
+                 np.ascontiguousarray(pixelMagnitudes)]
+        for a in (pixelTraces, distances):
+            if a is not None:
+                parts.append(np.ascontiguousarray(
+                    np.asarray(a).reshape(-1)[::61]))
         try:
             import xxhash
             h = xxhash.xxh3_64()
-            for a in (decodedImage, pixelMagnitudes):
-                h.update(np.ascontiguousarray(a).data)
+            for a in parts:
+                h.update(a.data)
             return h.intdigest()
         except ImportError:
             import zlib
             k = 0
-            for a in (decodedImage, pixelMagnitudes):
-                k = zlib.adler32(np.ascontiguousarray(a).data, k)
+            for a in parts:
+                k = zlib.adler32(a.data, k)
             return k
 
     def _remember(self, arrays, vol, key):
@@ -382,7 +392,8 @@ class PixelBasedDecoder(object):
         arrays' CURRENT contents: the arrays are the very objects an earlier
         call saw (identity) and either they are still the read-only arrays
         decode_pixels returned, or a checksum of decodedImage and
-        pixelMagnitudes taken at upload time still matches.  Anything else --
+        pixelMagnitudes (plus a strided sample of the traces and distances)
+        taken at upload time still matches.  Anything else --
         other arrays, arrays made writeable, edited contents -- is uploaded
         again, so the result always follows the arrays as the reference's
         does.  Entries whose arrays are gone are dropped."""
@@ -397,7 +408,8 @@ class PixelBasedDecoder(object):
             if key is None:
                 if not any(a.flags.writeable for a in (d, m, t, ds)):
                     return vol
-            elif key == self._content_key(decodedImage, pixelMagnitudes):
+            elif key == self._content_key(decodedImage, pixelMagnitudes,
+                                          pixelTraces, distances):
                 return vol
             self._recent = [e for e in self._recent if e[1] is not vol]
             break
@@ -430,7 +442,8 @@ class PixelBasedDecoder(object):
                 distances if distances is not None else pixelMagnitudes)
         if all(isinstance(a, np.ndarray) for a in keep):
             self._remember(keep, vol,
-                           self._content_key(decodedImage, pixelMagnitudes))
+                           self._content_key(decodedImage, pixelMagnitudes,
+                                             pixelTraces, distances))
         return vol
 
     # --------------------------------------------------------- region table --

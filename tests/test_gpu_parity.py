@@ -188,6 +188,31 @@ def test_decode_random_scale_factors(seed, gpu_device):
     assert_distances(d, od, gap, odi)
 
 
+@pytest.mark.parametrize('sigma', [0.1, 0.15, 0.2, 0.21, 0.25, 0.6])
+def test_narrow_gaussian_u16(sigma, gpu_device):
+    """lowPassSigma below ~0.21 gives ksize 3 with side taps that round to 0
+    and a centre tap of exactly 65536 in 16.16 fixed point (the identity);
+    just above it the side taps are tiny.  Both must match the oracle's exact
+    integer blur on uint16 input (the packed 16-bit taps of the row pass cannot
+    hold 65536)."""
+    from conftest import synth_stack
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    img = synth_stack(cb, (70, 130), 25, seed=3, amp=(500, 60000), bg=50)
+    img[0, :4, :4] = 65535            # saturated pixels at a border
+    sf = np.full(16, 900.0)
+    bg = np.zeros(16)
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.5176, 1, sigma)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(img, dm, sf, bg, 0.5176, 1,
+                                                   sigma, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert_distances(d, od, gap, odi)
+
+
 @pytest.mark.parametrize('case', ['b22_mhd4', 'b22_n1000_w4', 'b32_n3000_w4',
                                   'b32_n1500_mixed', 'b12_n1'])
 def test_large_and_odd_codebooks(case, gpu_device):
