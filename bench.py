@@ -9,9 +9,13 @@ table -> D2H of the records -> the reference's DataFrame.
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N          # no launcher: starts the N ranks itself
 
 With N ranks every rank decodes its own FOVs (FOVs are independent units,
-analysis/decode.py:71-72): weak scaling, no data-path collective.
+analysis/decode.py:71-72): weak scaling, no data-path collective.  The ranks
+RCCL saw are what the line reports as ``n_gpus``; ``--gpus`` must agree with
+the launcher's WORLD_SIZE, and without a launcher ``--gpus N`` spawns N fresh
+rank processes before anything touches a GPU.
 """
 import argparse
 import json
@@ -87,7 +91,13 @@ def cpu_baseline(codebook, img_plane, sf, bg, params):
             'fov_7z_s': r['extrapolated']['fov_7z_2048_s'],
             'extrapolated': True, 'cores': r['cores'],
             'host': r['cpu_model'] + ' (build container, not this host)',
-            'blur': r['blur'], 'source': 'profiles/cpu_reference_baseline.json'}
+            'blur': r['blur'], 'source': 'profiles/cpu_reference_baseline.json',
+            # the reference's extraction time grows with the number of regions:
+            # the plane it was timed on is sparser than the bench FOV's planes
+            'sample_barcodes_per_Mpx': r['measured'][-1]['barcodes']
+            / (r['measured'][-1]['pixels'] / 1e6),
+            'sample_decoded_px_fraction': r['measured'][-1]['decoded_px']
+            / r['measured'][-1]['pixels']}
     return out
 
 
@@ -149,6 +159,223 @@ def codebook_configs(dev):
     return out
 
 
+def spawn_ranks(n, argv):
+    """``--gpus N`` without a launcher: start the N rank processes ourselves.
+    The children are FRESH interpreters created before this process has made
+    any GPU call (device_count() does not initialise the GPU on this image);
+    the parent only waits and returns the worst exit code."""
+    import socket
+    import subprocess
+    backend = 'nccl'
+    for i, a in enumerate(argv):
+        if a == '--backend' and i + 1 < len(argv):
+            backend = argv[i + 1]
+        elif a.startswith('--backend='):
+            backend = a.split('=', 1)[1]
+    if backend == 'nccl':
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(
+                'bench.py: --gpus {} asked for but {} GPU(s) visible; RCCL needs '
+                'one GPU per rank (--backend gloo rehearses the multi-rank path '
+                'on fewer)\n'.format(n, have))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def timed_steady(task, fovs, sf, bg, steps, warmup, barrier):
+    """ONE run_fovs generator across warm-up and the timed window.  After
+    `warmup` yielded FOVs the pipeline is full (one FOV decoded, two with their
+    tables queued); the window then runs from a barrier + device sync to a
+    device sync + barrier around exactly `steps` more yields: every stage --
+    decode, labelling, table, frame rows, DataFrame -- executes `steps` times
+    inside it, nothing of the fill and nothing beyond the drain of the stages
+    it queued itself."""
+    import itertools
+    stacks = (fovs[i % len(fovs)] for i in itertools.count())
+    gen = task.run_fovs(stacks, sf, bg)
+    for _ in range(warmup):
+        next(gen)
+    barrier()
+    task.kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bc, vol = next(gen)
+    barrier()
+    dt = time.perf_counter() - t0
+    events, task.kernel_events = task.kernel_events, None
+    gen.close()
+    return dt, events, bc, vol
+
+
+def timed_cold(task, fovs, sf, bg, steps, barrier, serial=False):
+    """`steps` FOVs through a pipeline that starts empty and is drained inside
+    the window (r01/r02's definition of a step)."""
+    barrier()
+    task.kernel_events = []
+    t0 = time.perf_counter()
+    bc = vol = None
+    if serial:
+        for i in range(steps):
+            bc, vol = task.run_fov(fovs[i % len(fovs)], sf, bg, fov=i)
+    else:
+        for bc, vol in task.run_fovs((fovs[i % len(fovs)] for i in range(steps)),
+                                     sf, bg):
+            pass
+    barrier()
+    dt = time.perf_counter() - t0
+    events, task.kernel_events = task.kernel_events, None
+    return dt, events, bc, vol
+
+
+def config4(codebook, dev, rank, world, group_backend, n_fovs=400, F=50,
+            iterations=3, chunk=100, hw=(H, W), z=Z, spots=SPOTS_PER_PLANE):
+    """BASELINE configs[3] / SURVEY 8d config 4: `n_fovs` synthetic FOVs (seed
+    1234 + fov), FOV i on rank i mod world; first the scale-factor loop --
+    `iterations` chained OptimizeIteration passes of F random (fov, z)
+    fragments (seed 99 + pass), with optimize_background off and on, each pass
+    ending in the packed [F, 2B+N] all-reduce -- then Decode of every FOV with
+    the factors the last pass produced (decode.py:107-110), through
+    run_fovs_sharded.  FOVs are generated on the device outside the clocks, at
+    most `chunk` resident per rank at a time."""
+    import torch.distributed as dist
+    from merlin_amd import optimize
+    from merlin_amd.decode import Decode, shard_fovs
+    from merlin_amd.synthetic import synthetic_fov
+    dist_on = world > 1
+    bits = codebook.get_barcodes().shape[1]
+    h, w = hw
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist_on:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if not dist_on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64,
+                         device=dev if group_backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    fovs = list(range(n_fovs))
+
+    # ---- OptimizeIteration chain.  The draw of pass k is a function of the
+    # seed alone, so the planes this rank will be asked for are known: they are
+    # generated before the clock starts (the reference reads them from disk).
+    out = {'fovs': n_fovs, 'fragments_per_iteration': F, 'iterations': iterations,
+           'ranks': world}
+    planes = {}
+    draws = []
+    for k in range(iterations):
+        rng = np.random.RandomState(99 + k)
+        draws.append([[int(rng.choice(fovs)), int(rng.choice(list(range(z))))]
+                      for _ in range(F)])
+    for d in draws:
+        for i in optimize.shard_fragments(F, rank, world):
+            f, zz = d[i]
+            if (f, zz) not in planes:
+                planes[(f, zz)] = synthetic_fov(
+                    codebook.get_barcodes(), z, h, w, spots, SEED + f,
+                    dev)[:, zz].clone()
+    hist = optimize.pixel_histogram(torch.stack(list(planes.values()), 1)) \
+        if planes else torch.zeros((bits, 65534), dtype=torch.float64, device=dev)
+    init = optimize.initial_scale_factors(optimize.summed_pixel_histogram(hist))
+    for name, bgopt in (('optimize', False), ('optimize_background', True)):
+        params = {'fov_per_iteration': F, 'optimize_background': bgopt}
+        # untimed pass: streams, allocator, codebook table
+        optimize.run_optimize_chain(codebook, lambda f, zz: planes[(f, zz)], fovs, z,
+                                    init, 1, params, dev, None, 99)
+        barrier()
+        t0 = time.perf_counter()
+        chain = optimize.run_optimize_chain(
+            codebook, lambda f, zz: planes[(f, zz)], fovs, z, init, iterations,
+            params, dev, None, 99)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert [c.parameters['fov_index'] for c in chain] == draws
+        out[name] = {'ms_per_iteration': dt / iterations * 1e3,
+                     'ms_per_fragment': dt / iterations / F * 1e3,
+                     'scale_factors': [round(float(v), 3)
+                                       for v in chain[-1].get_scale_factors()],
+                     'barcodes_per_fragment': float(np.mean(
+                         chain[-1].get_barcode_count_history()[-1].sum()))}
+        if bgopt:
+            out[name]['backgrounds'] = [round(float(v), 3)
+                                        for v in chain[-1].get_backgrounds()]
+        else:
+            sf, bg = chain[-1].get_scale_factors(), chain[-1].get_backgrounds()
+    del planes
+
+    # the exchange step on its own (one [F, 2B+N] all-reduce)
+    N = codebook.get_barcodes().shape[0]
+    mine_f = optimize.shard_fragments(F, rank, world)
+    rng = np.random.default_rng(rank)
+    rf = rng.uniform(0.5, 1.5, (len(mine_f), bits))
+    bgr = rng.normal(size=(len(mine_f), bits))
+    seen = rng.integers(0, 50, (len(mine_f), N)).astype(np.float64)
+    for _ in range(3):
+        got = optimize.exchange_fragment_results(rf, bgr, seen, mine_f, F, dev)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        got = optimize.exchange_fragment_results(rf, bgr, seen, mine_f, F, dev)
+    torch.cuda.synchronize(dev)
+    out['exchange_us'] = max_over_ranks((time.perf_counter() - t1) / 20 * 1e6)
+    out['exchange_payload_bytes'] = F * (2 * bits + N) * 8
+    out['exchange_own_rows_intact'] = bool(
+        np.array_equal(got[0][mine_f], rf) and np.array_equal(got[2][mine_f], seen))
+
+    # ---- Decode of every FOV, sharded
+    task = Decode(codebook, {'crop_width': 100, 'distance_threshold': 0.5167,
+                             'lowpass_sigma': 1, 'minimum_area': 0}, device=dev)
+    mine = shard_fovs(fovs, rank, world)
+    total = 0.0
+    records = 0
+    for c0 in range(0, max(len(mine), 1), chunk):
+        part = mine[c0:c0 + chunk]
+        resident = {f: synthetic_fov(codebook.get_barcodes(), z, h, w, spots,
+                                     SEED + f, dev) for f in part}
+        if c0 == 0 and part:        # untimed: first-use allocations
+            for _ in task.run_fovs((resident[part[0]] for _ in range(4)), sf, bg):
+                pass
+        barrier()
+        t0 = time.perf_counter()
+        for f, bc, vol in task.run_fovs_sharded(
+                lambda f: resident[f], sf, bg, part, rank=0, world=1):
+            records += len(bc)
+        barrier()
+        total += time.perf_counter() - t0
+        del resident
+    total = max_over_ranks(total)
+    if dist_on:
+        t = torch.tensor([records], dtype=torch.float64,
+                         device=dev if group_backend == 'nccl' else 'cpu')
+        dist.all_reduce(t)
+        records = int(t.item())
+    out['decode'] = {'seconds': total, 'fovs_per_sec': n_fovs / total,
+                     'Mpx_per_s': n_fovs * z * h * w / total / 1e6,
+                     'ms_per_fov_per_gpu': total / max(len(mine), 1) * 1e3,
+                     'records': records,
+                     'scale_factors_from': 'optimize (3rd pass)'}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -158,18 +385,66 @@ def main():
     ap.add_argument('--no-host-pipeline', action='store_true')
     ap.add_argument('--no-preprocess', action='store_true')
     ap.add_argument('--no-codebooks', action='store_true')
+    ap.add_argument('--no-config4', action='store_true')
+    ap.add_argument('--no-image-output', action='store_true')
+    ap.add_argument('--config4-fovs', type=int, default=400)
+    ap.add_argument('--config4-fragments', type=int, default=50)
+    ap.add_argument('--config4-size', type=int, default=H,
+                    help='FOV edge in pixels for config 4 (tests use small FOVs)')
     ap.add_argument('--backend', default='nccl',
                     help='torch.distributed backend for --gpus > 1 (nccl = RCCL; '
                          'gloo only to rehearse the multi-rank path on one GPU)')
     ap.add_argument('--serial', action='store_true',
                     help='one run_fov call per step instead of the pipelined run_fovs')
+    ap.add_argument('--rendezvous-only', action='store_true',
+                    help='start the ranks, all-reduce once, print n_gpus and exit '
+                         '(checks the launch path; touches no GPU with gloo)')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no launcher: be the launcher.  Nothing has touched a GPU yet.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus {} but the launcher started {} rank(s) '
+                         '(WORLD_SIZE)\n'.format(args.gpus, world))
+        sys.exit(2)
     dist_on = world > 1
-    local_rank %= max(torch.cuda.device_count(), 1)
+
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        n = 1
+        if dist_on:
+            if args.backend == 'nccl':
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+                t = torch.ones(1, device='cuda')
+            else:
+                dist.init_process_group(args.backend)
+                t = torch.ones(1)
+            dist.all_reduce(t)
+            n = int(t.item())
+            assert n == dist.get_world_size()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'n_gpus': n, 'rendezvous_only': True,
+                              'backend': args.backend}))
+        return
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.stderr.write('bench.py: no GPU visible\n')
+        sys.exit(2)
+    if dist_on and args.backend == 'nccl' and n_dev < world:
+        sys.stderr.write('bench.py: {} ranks but {} GPU(s) visible; RCCL needs one GPU '
+                         'per rank\n'.format(world, n_dev))
+        sys.exit(2)
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if dist_on:
@@ -178,6 +453,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        world = dist.get_world_size()       # the ranks RCCL actually connected
 
     from merlin_amd.decode import Decode
     from merlin_amd.synthetic import synthetic_fov
@@ -194,76 +470,45 @@ def main():
     sf = initial_scale_factors(fovs[0])
     bg = np.zeros(B)
 
-    def run(count):
-        # a step = one FOV through Decode.run_fovs (stack in HBM -> barcode
-        # DataFrame on the host); run_fovs overlaps FOV k's PCIe/host tail
-        # with FOV k+1's kernels, and every FOV's DataFrame is complete
-        # before the loop ends
-        bc = vol = None
-        stacks = (fovs[i % 2] for i in range(count))
-        for bc, vol in task.run_fovs(stacks, sf, bg):
-            pass
-        return bc, vol
-
     def barrier():
         torch.cuda.synchronize(dev)
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.serial:                          # one run_fov call per step
-        def run(count):                      # noqa: F811
-            bc = vol = None
-            for i in range(count):
-                bc, vol = task.run_fov(fovs[i % 2], sf, bg, fov=i)
-            return bc, vol
-
-    if args.warmup:
-        run(args.warmup)
-    barrier()
-    task.kernel_events = []          # HIP events around every decode launch
-    t0 = time.perf_counter()
-    bc, vol = run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    k_events, task.kernel_events = task.kernel_events, None
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64,
+    def max_over_ranks(x):
+        if not dist_on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64,
                          device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
 
+    # table / staging buffers are carved from torch's caching allocator: give it
+    # its working set up front (three FOVs in flight) so that no timed FOV pays a
+    # hipMalloc because it is a little larger than every block cached so far
+    task.reserve_memory(fovs[0].shape)
+
+    # A step = one FOV through Decode.run_fovs (stack in HBM -> barcode DataFrame
+    # on the host).  Steady state: `steps` FOVs through a full pipeline; cold:
+    # the same count through a pipeline that fills and drains inside the window.
+    steady = not args.serial and args.warmup >= 4
+    if steady:
+        dt, k_events, bc, vol = timed_steady(task, fovs, sf, bg, args.steps,
+                                             args.warmup, barrier)
+    else:
+        if args.warmup:
+            timed_cold(task, fovs, sf, bg, args.warmup, barrier, args.serial)
+        dt, k_events, bc, vol = timed_cold(task, fovs, sf, bg, args.steps, barrier,
+                                           args.serial)
+    dt = max_over_ranks(dt)
     n_records = len(bc)
     n_decoded = int((vol.decoded >= 0).sum())
     del bc, vol
-
-    # ---- the one collective of the path (outside the timed decode loop, which
-    # has none): OptimizeIteration's exchange of the per-fragment refactors,
-    # background refactors and barcode counts (optimize.py:328-345, 358-373,
-    # 406-408) as ONE packed [F, 2B+N] sum-all-reduce over RCCL ----
-    exchange = None
-    if dist_on:
-        from merlin_amd import optimize
-        F, N = 50, 140
-        mine = optimize.shard_fragments(F, rank, world)
-        rng = np.random.default_rng(rank)
-        rf, bgr = rng.uniform(0.5, 1.5, (len(mine), B)), rng.normal(size=(len(mine), B))
-        seen = rng.integers(0, 50, (len(mine), N)).astype(np.float64)
-        for _ in range(3):
-            got = optimize.exchange_fragment_results(rf, bgr, seen, mine, F, dev)
-        barrier()
-        t1 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            got = optimize.exchange_fragment_results(rf, bgr, seen, mine, F, dev)
-        torch.cuda.synchronize(dev)
-        ex_us = (time.perf_counter() - t1) / reps * 1e6
-        ok = bool(np.array_equal(got[0][mine], rf) and np.array_equal(got[2][mine], seen))
-        exchange = {'rccl_ranks': world, 'backend': args.backend,
-                    'exchange_us': ex_us,
-                    'payload_bytes': F * (2 * B + N) * 8, 'own_rows_intact': ok,
-                    'note': 'one packed [F, 2B+N] float64 all-reduce per '
-                            'OptimizeIteration, host numpy in -> host numpy out'}
+    dt_cold = None
+    if steady:
+        dt_cold = max_over_ranks(timed_cold(task, fovs, sf, bg, args.steps,
+                                            barrier)[0])
 
     # ---- roofline of the dominant kernel (decode_kernel): HIP events around
     # each of its launches inside the timed region, on the stream the library
@@ -285,13 +530,15 @@ def main():
     torch.cuda.synchronize(dev)
     k_alone_ms = e0.elapsed_time(e1) / 20
     del v
-    # algorithmic bytes per pixel: 2B in (u16 stack) + 2 (int16 id) + 4
-    # (magnitude) + 8 (float64 distance) = 2B + 14, plus 4B of normalised
-    # traces for every decoded pixel (the FOV path keeps no others)
-    alg_bytes = px_fov * (2 * B + 14) + n_decoded * 4 * B
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    # SURVEY 8d's figure: 2B + 10 per pixel (float32 distances, no traces)
+    # ALGORITHMIC bytes per launch, SURVEY 8d: 2B (u16 stack) + 2 (int16 id) + 4
+    # (magnitude) + 4 (distance) = 2B + 10 = 42 B per pixel x the 29 360 128
+    # pixels one launch decodes.  `roofline.achieved` / `frac` use this figure.
     survey_bytes = px_fov * (2 * B + 10)
+    achieved = survey_bytes / (k_ms * 1e-3) / 1e9
+    # What this implementation has to move for the reference's outputs: float64
+    # distances (+4) and 4B of normalised traces per DECODED pixel (the region
+    # table reads them): reported as frac_impl_bytes.
+    impl_bytes = px_fov * (2 * B + 14) + n_decoded * 4 * B
 
     # HBM bytes and VALU instructions per launch come from PMC counters, which
     # need separate rocprofv3 --pmc passes (dev/profile.sh, dev/
@@ -326,11 +573,13 @@ def main():
         else:
             stale.append('profiles/decode_counters.json')
 
+    single = rank == 0 and world == 1
+
     # ---- PCIe-inclusive rate (never `value`): the same FOVs starting in
     # page-locked HOST memory, uploaded by the pinned multi-buffered pipeline
     # (Decode.run_fovs_from_host) one FOV ahead of the kernels ----
     host_line = None
-    if rank == 0 and world == 1 and not args.no_host_pipeline:
+    if single and not args.no_host_pipeline:
         hosts = [f.cpu().pin_memory() for f in fovs]
         n_host = max(4, min(args.steps, 20))
         for _ in task.run_fovs_from_host((hosts[i % 2] for i in range(3)), sf, bg):
@@ -347,11 +596,47 @@ def main():
                              'H2D of FOV k+1 overlaps the kernels of FOV k'}
         del hosts
 
+    # ---- the reference's default: write_decoded_images (decode.py:47-48,
+    # 165-168) -- one 352 MB float32 hyperstack per FOV leaves the GPU and goes
+    # to disk.  The headline step has no output directory; this is the same
+    # loop with one. ----
+    image_line = None
+    if single and not args.no_image_output:
+        import shutil
+        import tempfile
+        outdir = tempfile.mkdtemp(prefix='mf_bench_img_')
+        try:
+            wtask = Decode(codebook, params, device=dev, outputDirectory=outdir)
+            n_img = 6
+            for _ in wtask.run_fovs((fovs[i % 2] for i in range(2)), sf, bg):
+                pass
+            wtask.flush_images()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in wtask.run_fovs((fovs[i % 2] for i in range(n_img)), sf, bg,
+                                    fovs=list(range(n_img))):
+                pass
+            wtask.flush_images()
+            torch.cuda.synchronize(dev)
+            it = (time.perf_counter() - t1) / n_img
+            nbytes = os.path.getsize(os.path.join(outdir, 'decoded_0.tif'))
+            image_line = {'ms_per_fov': it * 1e3, 'fovs': n_img,
+                          'file_bytes_per_fov': nbytes,
+                          'GB_per_s_to_disk': nbytes / it / 1e9,
+                          'directory': 'tempfile.mkdtemp()',
+                          'note': 'run_fovs with outputDirectory set: float32 (decoded, '
+                                  'magnitude, distance) hyperstack per FOV, D2H + file '
+                                  'write included; every file complete before the clock '
+                                  'stops'}
+            del wtask
+        finally:
+            shutil.rmtree(outdir, ignore_errors=True)
+
     # ---- the stage in front of the decoder, reported beside
     # the headline number: high-pass + 20 float64 Lucy-Richardson iterations per
     # 2048 x 2048 camera frame (112 frames make one FOV) ----
     pre_line = None
-    if rank == 0 and world == 1 and not args.no_preprocess:
+    if single and not args.no_preprocess:
         from merlin_amd.preprocess import DeconvolutionPreprocess
         n_frames = B * Z                          # one FOV's camera frames
         g = torch.Generator(device=dev).manual_seed(SEED)
@@ -369,7 +654,7 @@ def main():
         p1.record()
         torch.cuda.synchronize(dev)
         ms_frame = p0.elapsed_time(p1) / 3 / n_frames
-        # bytes this implementation must move (646 B/px), and the
+        # bytes this implementation must move (630 B/px), and the
         # r01 figure (every iteration 34 B + an initialisation pass: 720 B/px)
         from merlin_amd.preprocess import algorithmic_bytes_per_pixel
         pre_bytes = algorithmic_bytes_per_pixel(20) * H * W
@@ -386,6 +671,16 @@ def main():
         del frames, pre
         torch.cuda.empty_cache()
 
+    del fovs
+    torch.cuda.empty_cache()
+    cfg4 = None
+    if not args.no_config4:
+        cfg4 = config4(codebook, dev, rank, world, args.backend,
+                       n_fovs=args.config4_fovs, F=args.config4_fragments,
+                       hw=(args.config4_size, args.config4_size),
+                       spots=max(1, SPOTS_PER_PLANE * args.config4_size ** 2
+                                 // (H * W)))
+
     if rank == 0:
         mpx = world * args.steps * px_fov / dt / 1e6
         out = {
@@ -397,10 +692,17 @@ def main():
             'vs_baseline': None, 'dtype': 'u16/f32/f64',
             'data': 'synthetic',
             'fovs_per_sec': world * args.steps / dt,
+            'timing': ('steady: one run_fovs pipeline kept full across warm-up and the '
+                       'timed window; {} FOVs yielded (DataFrames complete) and {} of '
+                       'every stage executed between two barrier + device syncs'
+                       .format(args.steps, args.steps)) if steady else
+                      ('cold: the pipeline fills and drains inside the window'
+                       + (' (--serial: one run_fov per step)' if args.serial else '')),
             'config': {
                 'workload': 'single FOV 2048x2048x7 z-planes, 16-bit MHD4 '
                             'codebook (140 codewords), u16 stack resident in '
-                            'HBM -> barcode DataFrame on host',
+                            'HBM -> barcode DataFrame on host; no decoded-image '
+                            'files (see with_image_output)',
                 'bits': B, 'z': Z, 'h': H, 'w': W, 'codewords': 140,
                 'spots_per_plane': SPOTS_PER_PLANE,
                 'records_per_fov': n_records, 'decoded_px_per_fov': n_decoded,
@@ -409,28 +711,45 @@ def main():
                 'bound': 'hbm', 'kernel': 'decode_kernel<u16,R=2,B<=16>',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'frac_survey_bytes': survey_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                'survey_bytes': survey_bytes, 'valu': valu,
+                'algorithmic_bytes': survey_bytes,
+                'bytes_per_px': 2 * B + 10,
+                'frac_impl_bytes': impl_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'impl_bytes': impl_bytes, 'valu': valu,
                 'stale_counter_files': stale,
                 'kernel_ms': k_ms, 'launches_timed': len(k_events),
                 'alone': {'kernel_ms': k_alone_ms,
-                          'achieved': alg_bytes / (k_alone_ms * 1e-3) / 1e9,
-                          'frac': alg_bytes / (k_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'achieved': survey_bytes / (k_alone_ms * 1e-3) / 1e9,
+                          'frac': survey_bytes / (k_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'frac_impl_bytes': impl_bytes / (k_alone_ms * 1e-3) / 1e9
+                          / HBM_PEAK_GBS,
                           'note': 'same kernel back to back on an otherwise idle GPU; '
                                   'in the timed region it overlaps the previous '
-                                  "FOV's region-table stage"},
-                'algorithmic_bytes': alg_bytes},
+                                  "FOV's region-table stage"}},
         }
+        if dt_cold is not None:
+            out['ms_per_step_cold'] = dt_cold / args.steps * 1e3
         if host_line is not None:
             out['host_pipeline'] = host_line
+        if image_line is not None:
+            out['with_image_output'] = image_line
         if pre_line is not None:
             out['preprocess'] = pre_line
-        if exchange is not None:
-            out['optimize_exchange'] = exchange
+        if cfg4 is not None:
+            out['config4'] = cfg4
+        if dist_on:
+            out['optimize_exchange'] = {
+                'rccl_ranks': world, 'backend': args.backend,
+                'exchange_us': cfg4['exchange_us'] if cfg4 else None,
+                'payload_bytes': cfg4['exchange_payload_bytes'] if cfg4 else None,
+                'note': 'one packed [F, 2B+N] float64 all-reduce per '
+                        'OptimizeIteration, host numpy in -> host numpy out'}
         if world == 1 and not args.no_codebooks:
             out['codebooks'] = codebook_configs(dev)
         if not args.no_cpu_baseline and world == 1:
-            plane = fovs[0][:, 0].cpu().numpy()
+            fov0 = synthetic_fov(codebook.get_barcodes(), Z, H, W, SPOTS_PER_PLANE,
+                                 SEED, dev)
+            plane = fov0[:, 0].cpu().numpy()
+            del fov0
             out['cpu_baseline'] = cpu_baseline(codebook, plane, sf, bg,
                                                task.parameters)
         print(json.dumps(out))

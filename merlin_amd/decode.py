@@ -87,6 +87,50 @@ class Decode(object):
                 self._tbl = torch.cuda.Stream(dev)
         return self._tbl
 
+    def _label_stream(self, dev):
+        """Third compute stream: the labelling of the pipelined FOV loop."""
+        if not self.overlap:
+            return None
+        if getattr(self, '_lbl', None) is None:
+            with torch.cuda.device(dev):
+                self._lbl = torch.cuda.Stream(dev)
+        return self._lbl
+
+    def reserve_memory(self, stackShape, fovsInFlight=None):
+        """Give torch's caching allocator the working set of the FOV loop up
+        front: one block per stream of the pipeline (the allocator keeps a pool
+        per stream), allocated and released at once, from which the per-FOV
+        images, label volumes, tables and staging buffers are then carved.
+        Without it the pool grows by a hipMalloc (5-8 ms) whenever a FOV needs a
+        slightly larger table than any before it.  Optional; sizes are upper
+        estimates for ``stackShape`` = (B, Z, H, W) and are capped at half the
+        free memory."""
+        B, Z, H, W = (int(v) for v in stackShape)
+        px = Z * H * W
+        n = fovsInFlight or (self.decodeAhead + self.frameLag + 2)
+        dev = self.decoder._dev()
+        sizes = [(None, px * (2 + 4 + 8 + 4 * B) * n),
+                 (self._label_stream(dev), (px * 4 + (1 << 20)) * n),
+                 (self._table_stream(dev), px * 24 * (self.frameLag + 1)),
+                 (self._side_stream(dev), px * 4 * (self.frameLag + 1))]
+        with torch.cuda.device(dev):
+            free = torch.cuda.mem_get_info(dev)[0]
+            scale = min(1.0, 0.5 * free / max(sum(b for _, b in sizes), 1))
+            for stream, nbytes in sizes:
+                nbytes = int(nbytes * scale)
+                if stream is None:
+                    if nbytes:
+                        torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                elif nbytes:
+                    with torch.cuda.stream(stream):
+                        torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+    def flush_images(self):
+        """Wait until every decoded-image file queued so far is on disk."""
+        w = getattr(self, '_image_writer', None)
+        if w is not None:
+            w.flush()
+
     def decode_fov_device(self, imageStack: torch.Tensor, scaleFactors,
                           backgrounds, returnTraces='decoded'
                           ) -> DecodedVolume:
@@ -227,10 +271,7 @@ class Decode(object):
         typed = database is not None
         xy64 = globalAligner is not None
         if side is not None and self._table_stream(dev) is not None:
-            if getattr(self, '_lbl', None) is None:
-                with torch.cuda.device(dev):
-                    self._lbl = torch.cuda.Stream(dev)
-            lbl = self._lbl
+            lbl = self._label_stream(dev)
         from collections import deque
         decoded = deque()   # (vol, labels pending, fov): stage 1 queued
         tabled = deque()    # (vol, frame pending, fov): stage 2 queued

@@ -370,3 +370,30 @@ class OptimizeIteration(object):
             return np.array([countsMean])
         return np.append(self._previous.get_barcode_count_history(),
                          [countsMean], axis=0)
+
+
+def run_optimize_chain(codebook, imageProvider, fovs, zCount,
+                       initialScaleFactors, iterations=3, parameters=None,
+                       device=None, group=None, seed=None):
+    """``iterations`` chained OptimizeIteration passes, the way an analysis
+    JSON chains them through ``previous_iteration`` (optimize.py:61-62,
+    158-165; the reference's test run chains two,
+    test/auxiliary_files/test_analysis_parameters.json:17-41): every pass draws
+    its own ``fov_per_iteration`` random (fov, z) fragments (optimize.py:43-50;
+    ``seed + k`` for pass k when a seed is given), shards them over the ranks
+    of ``group`` and ends in the one exchange step.  Returns the list of
+    completed iterations; the last one's get_scale_factors() /
+    get_backgrounds() are what Decode uses (decode.py:107-110)."""
+    done = []
+    prev = None
+    for k in range(iterations):
+        it = OptimizeIteration(
+            codebook, parameters, fovs=fovs, zCount=zCount,
+            previousIteration=prev,
+            initialScaleFactors=initialScaleFactors if prev is None else None,
+            imageProvider=imageProvider, device=device, group=group,
+            seed=None if seed is None else seed + k)
+        it.run()
+        done.append(it)
+        prev = it
+    return done
