@@ -26,16 +26,18 @@
 //  * Nearest codeword: MERFISH codebooks are binary, so the score of codeword n
 //    is v_n * sum_{on bits} x_b - |c_n|^2/2.  The sum over on-bits is a
 //    [codewords x bits] x [bits x pixels] product with a 0/-t matrix: it runs on
-//    the matrix cores (v_mfma_f32_32x32x16_bf16) with x split exactly into
-//    three bf16 terms, so the products are exact and only the float32
-//    accumulation rounds.  The accumulator is the key (a float that grows with
-//    the distance); each lane keeps the running minimum -- and the runner-up
-//    unless the codebook's minimum distance rules a second candidate out
-//    (EXCL) -- over its accumulator registers, 32-codeword tiles one after the
-//    other; the two lanes that share a pixel merge through v_permlane32_swap.
-//    The winner's distance is recomputed in float64 exactly as the reference
-//    does, and a pixel whose top two keys are closer than TIE_EPS is re-decided
-//    by an exact float64 scan whenever it could pass the distance threshold.
+//    the matrix cores (v_mfma_f32_32x32x16_f16) with 1024 x split into two
+//    float16 terms (22 significant bits; r02 used three exact bfloat16 terms
+//    and half as many again matrix instructions), float32 accumulation.  The
+//    accumulator is the key (a float that
+//    grows with the distance); each lane keeps the running minimum -- and the
+//    runner-up unless the codebook's minimum distance rules a second candidate
+//    out (EXCL) -- over its accumulator registers, 32-codeword tiles one after
+//    the other; the two lanes that share a pixel merge through
+//    v_permlane32_swap.  The winner's distance is recomputed in float64 exactly
+//    as the reference does, and a pixel whose top two keys are closer than
+//    TIE_EPS is re-decided by an exact float64 scan whenever it could pass the
+//    distance threshold.
 //
 // Built with -ffp-contract=off: every float op below is the single IEEE
 // operation it is written as; fused multiply-adds are explicit fmaf() calls.
@@ -67,6 +69,18 @@ constexpr float TIE_EPS = MF_TIE_EPS;   // score gap below which float64 decides
 constexpr double TIE_D2_MARGIN = 1.0e-4;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// Operands of the codeword search: 1 = x * 2^10 split into two float16 terms
+// (round to nearest; 22 significant bits, the scaling keeps the low term out
+// of the float16 subnormals), v_mfma_f32_32x32x16_f16, two matrix instructions
+// per 32 x 32 tile; 0 = r02's exact three-term bfloat16 split, three
+// instructions per tile.  The table built by mf_codebook_prepare matches.
+#ifndef MF_SPLIT_F16
+#define MF_SPLIT_F16 1
+#endif
+constexpr int NSPLIT = MF_SPLIT_F16 ? 2 : 3;
+constexpr float X_SCALE = MF_SPLIT_F16 ? 1024.0f : 1.0f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -149,6 +163,39 @@ __device__ __forceinline__ float fmin3(float a, float b, float c)
     float r;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// IEEE square root of a squared distance.  The compiler's float64 sqrt is this
+// Newton sequence wrapped in a rescaling for arguments below 2^-767; a sum of
+// squares of differences of float32 values is either 0 or at least 2^-298, so
+// the rescaling (two ldexp, a compare, two selects) never acts and is left out:
+// same bits for every argument this kernel produces.
+__device__ __forceinline__ double sqrt_d2(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double e = __builtin_fma(-g, g, a);
+    g = __builtin_fma(e, h, g);
+    e = __builtin_fma(-g, g, a);
+    g = __builtin_fma(e, h, g);
+    // 0 and +inf (no real codeword: d2 = INFINITY) map to themselves
+    return (a == 0.0 || a == INFINITY) ? a : g;
+}
+
+// one 32 x 32 x 16 matrix instruction: codeword rows x 16 bits x pixel columns
+__device__ __forceinline__ f32x16 mfma_tile(u32x4 a, u32x4 b, f32x16 c)
+{
+#if MF_SPLIT_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 // EXCL: the codebook and the threshold guarantee that no pixel has two
@@ -261,6 +308,13 @@ constexpr bool tiles_in_sequence(int maxb) { return maxb <= 16 ? MF_SEQ16 : MF_S
 #define MF_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define MF_FENCE() ((void)0)
+#endif
+
+// timing-only ablations (wrong results): no workgroup barriers in the blur
+#ifdef MF_ABL_NOBARRIER
+#define MF_TILE_SYNC() ((void)0)
+#else
+#define MF_TILE_SYNC() __syncthreads()
 #endif
 
 // exact float64 squared distance between the normalised trace and codeword
@@ -409,18 +463,37 @@ decode_kernel(const DecodeArgs a)
         // offset voff[k] (one register per task, worked out before the tile
         // loop) from a base that is uniform over the workgroup.
         auto prefetch = [&](int g) {
+#ifdef MF_ABL_NOLOAD
+#pragma unroll
+            for (int k = 0; k < NTASK; ++k)
+#pragma unroll
+                for (int d = 0; d < WDW; ++d) win[k][d] = 0x00640064u + (uint32_t)(tid & 7) + g;
+            return;
+#endif
             if (interior) {
+#ifdef MF_ABL_HOTLOAD   // timing only: every tile reads the windows of one fixed tile (cache hits)
+                const char *gbase = reinterpret_cast<const char *>(img) +
+                                    ((int64_t)(g * GROUP) * a.bit_stride +
+                                     (int64_t)(64 - R) * W + (64 - RA)) * (int64_t)sizeof(PIX);
+#else
                 const char *gbase = reinterpret_cast<const char *>(img) +
                                     ((int64_t)(g * GROUP) * a.bit_stride + (int64_t)z * a.z_stride +
                                      (int64_t)(y0 - R) * W + (x0 - RA)) * (int64_t)sizeof(PIX);
+#endif
                 // every task of the group carries a real bit (the usual case:
                 // B a multiple of the group): plain loads, no lane masks
                 if (TASKS == NTASK * NTHREADS && (FULL || (g + 1) * GROUP <= MF_OPQ(B))) {
 #pragma unroll
                     for (int k = 0; k < NTASK; ++k) {
+#ifdef MF_ABL_ALIGNLOAD   // timing only: every window 16-byte aligned (wrong pixels)
+                        const u32x4 w4 = *reinterpret_cast<const u32x4 *>(
+                            reinterpret_cast<uintptr_t>(gbase + voff[k]) & ~uintptr_t(15));
+                        win[k][0] = w4.x; win[k][1] = w4.y; win[k][2] = w4.z; win[k][3] = w4.w;
+#else
                         const uint32_t *src = reinterpret_cast<const uint32_t *>(gbase + voff[k]);
 #pragma unroll
                         for (int d = 0; d < WDW; ++d) win[k][d] = src[d];
+#endif
                     }
                     return;
                 }
@@ -479,6 +552,10 @@ decode_kernel(const DecodeArgs a)
         // ---- horizontal pass from the register windows into LDS ----
         auto hpass = [&](int g) {
             HT *hs = hs0 + (g % HS_BUFFERS) * (GROUP * RH * TW);
+#ifdef MF_ABL_NOHPASS
+            if (win[0][0] == 0x12345u) hs[tid] = (HT)win[1][1];
+            return;
+#endif
 #pragma unroll
             for (int k = 0; k < NTASK; ++k) {
                 const int q = tid + k * NTHREADS;
@@ -550,7 +627,7 @@ decode_kernel(const DecodeArgs a)
         for (int g = 0; g < NG; ++g) {
             if (g * GROUP < MF_OPQ(B)) {
                 hpass(g);
-                __syncthreads();
+                MF_TILE_SYNC();
                 const HT *hs = hs0 + (g % HS_BUFFERS) * (GROUP * RH * TW);
                 if (g + 1 < NG && (g + 1) * GROUP < MF_OPQ(B)) prefetch(g + 1);
                 // ---- vertical pass for this thread's PPT pixels ----
@@ -564,13 +641,20 @@ decode_kernel(const DecodeArgs a)
                     for (int j = 0; j < PPT + 2 * R; ++j)
                         col[j] = hs[(i * RH + wave * PPT + j) * TW + lane];
                     double cd[PPT + 2 * R];
+#ifndef MF_ABL_NOVPASS
                     if constexpr (IS_U16 && MF_VPASS_F64) {
 #pragma unroll
                         for (int j = 0; j < PPT + 2 * R; ++j) cd[j] = (double)col[j];
                     }
+#endif
 #pragma unroll
                     for (int o = 0; o < PPT; ++o) {
                         float v;
+#ifdef MF_ABL_NOVPASS
+                        if constexpr (IS_U16) {
+                            v = (float)(col[o + R] >> 16);
+                        } else
+#endif
                         if constexpr (IS_U16 && MF_VPASS_F64) {
                             // V = sum k_j * H_j < 2^48 is exact in float64 (H < 2^32,
                             // pair sums < 2^33, taps < 2^16); V * 2^-32 + 0.5 is exact
@@ -629,7 +713,7 @@ decode_kernel(const DecodeArgs a)
                     }
                     MF_FENCE();
                 }
-                if constexpr (HS_BUFFERS == 1) __syncthreads();   // hs is rewritten by the next group
+                if constexpr (HS_BUFFERS == 1) MF_TILE_SYNC();   // hs is rewritten by the next group
             } else {
 #pragma unroll
                 for (int i = 0; i < GROUP; ++i)
@@ -705,17 +789,30 @@ decode_kernel(const DecodeArgs a)
             for (int tt = 0; tt < 2; ++tt) {
                 st[tt].best = KEY_INIT; st[tt].second = KEY_INIT; st[tt].tile = 0;
             }
-            uint32_t pk[3][KS][8];
+            uint32_t pk[NSPLIT][KS][8];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 float r[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) r[j] = x[o][16 * ks + j];
+                if constexpr (MF_SPLIT_F16) {
+                    // hi = RN16(1024 x), lo = RN16(1024 x - hi): the residual is
+                    // exact in float32, so x ~ (hi + lo) / 1024 to 2^-22 relative;
+                    // one v_cvt_pk_f16_f32 packs the two bits a B-operand dword holds
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        const f32x2 xs = (f32x2){r[2 * d], r[2 * d + 1]} * X_SCALE;
+                        const f16x2 hi = __builtin_convertvector(xs, f16x2);
+                        const f32x2 lo = xs - __builtin_convertvector(hi, f32x2);
+                        pk[0][ks][d] = __builtin_bit_cast(uint32_t, hi);
+                        pk[1][ks][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, f16x2));
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
 #pragma unroll
                     for (int d = 0; d < 8; ++d)
-                        pk[s][ks][d] = __builtin_amdgcn_perm(__float_as_uint(r[2 * d + 1]),
+                        pk[s % NSPLIT][ks][d] = __builtin_amdgcn_perm(__float_as_uint(r[2 * d + 1]),
                                                              __float_as_uint(r[2 * d]), 0x07060302u);
                     if (s < 2) {
                         // residual after the bf16 truncation (exact), two
@@ -730,8 +827,9 @@ decode_kernel(const DecodeArgs a)
                         }
                     }
                 }
+                }
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NSPLIT; ++s)
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         auto sw = __builtin_amdgcn_permlane32_swap(pk[s][ks][d], pk[s][ks][4 + d],
@@ -753,7 +851,8 @@ decode_kernel(const DecodeArgs a)
                     __syncthreads();
                 }
                 for (int ct = 0; ct < cn; ct += 32) {
-                    // A operand: 8 bf16 of codeword (ct + lane&31), bits 16ks + 8*half ..
+                    const int rows_left = a.N - (c0 + ct);     // real codewords from this tile on
+                    // A operand: 8 elements of codeword (ct + lane&31), bits 16ks + 8*half ..
                     u32x4 af[KS];
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
@@ -772,17 +871,19 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                            for (int s = 0; s < 3; ++s) {
+                            for (int s = 0; s < NSPLIT; ++s) {
                                 u32x4 bv;
                                 bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
                                 bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
-                                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, bv),
-                                    acc1, 0, 0, 0);
+                                acc1 = mfma_tile(af[ks], bv, acc1);
                             }
                         const float before = st[tt].best;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
+                            // rows 16-31 of the codebook's last tile are padding
+                            // when at most 16 codewords are left: accumulator
+                            // slots 8-15 (gq 2, 3) cannot win
+                            if (gq == 2 && rows_left <= 16) break;
                             float s4[4];
                             if constexpr (UNI) {
 #pragma unroll
@@ -817,13 +918,11 @@ decode_kernel(const DecodeArgs a)
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                            for (int s = 0; s < 3; ++s) {
+                            for (int s = 0; s < NSPLIT; ++s) {
                                 u32x4 bv;
                                 bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
                                 bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
-                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    __builtin_bit_cast(bf16x8, af[ks]), __builtin_bit_cast(bf16x8, bv),
-                                    acc[tt], 0, 0, 0);
+                                acc[tt] = mfma_tile(af[ks], bv, acc[tt]);
                             }
                     }
                     // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of
@@ -834,6 +933,7 @@ decode_kernel(const DecodeArgs a)
                         const float before = st[tt].best;
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
+                            if (gq == 2 && rows_left <= 16) break;   // padding rows, see above
                             float s4[4];
                             if constexpr (UNI) {
 #pragma unroll
@@ -916,7 +1016,7 @@ decode_kernel(const DecodeArgs a)
                     if (e < d2) { d2 = e; win = n; }
                 }
             }
-            const double d = sqrt(d2);
+            const double d = sqrt_d2(d2);
 
             const int gy = y0 + wave * PPT + o, gx = x0 + lane;
 #ifdef MF_ABL_NOSTORE
@@ -924,7 +1024,10 @@ decode_kernel(const DecodeArgs a)
 #else
             if (gy < H && gx < W) {
 #endif
-                const int64_t pix = ((int64_t)z * H + gy) * W + gx;
+                // the volume has fewer than 2^31 pixels (checked by the host): the
+                // pixel index is 32-bit arithmetic, one shift-add per output array
+                const uint32_t pin = (uint32_t)gy * (uint32_t)W + (uint32_t)gx;
+                const uint32_t pix = (uint32_t)z * (uint32_t)(H * W) + pin;
                 int16_t code = d <= a.dthr ? (int16_t)win : (int16_t)-1;
                 if (mag[o] < a.mthr) code = -1;
                 a.decoded[pix] = code;
@@ -932,7 +1035,7 @@ decode_kernel(const DecodeArgs a)
                 if (a.dist_f64) reinterpret_cast<double *>(a.dist)[pix] = d;
                 else reinterpret_cast<float *>(a.dist)[pix] = (float)d;
                 if (a.traces && (!a.tr_decoded_only || code >= 0)) {
-                    float *tp = a.traces + (int64_t)z * a.tr_z + ((int64_t)gy * W + gx) * a.tr_p;
+                    float *tp = a.traces + (int64_t)z * a.tr_z + (int64_t)pin * a.tr_p;
                     // (B and the bit stride taken as new here: otherwise one lane
                     // mask and one offset per bit are hoisted out of the tile loop
                     // and live in spilled scalar registers)
@@ -1143,17 +1246,20 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
                                     "codeword %d is not binary-valued (entries %g and %g)", n, v, c);
                 v = c;
                 m |= 1u << b;
-                // bf16 -1.0, or -0.5 above 16 bits
+                // -1.0, or -0.5 above 16 bits, as float16 (bfloat16 for the
+                // three-term split)
                 if (h.KB == 16)
-                    am[(size_t)n * 16 + b] = 0xbf80;
+                    am[(size_t)n * 16 + b] = MF_SPLIT_F16 ? 0xbc00 : 0xbf80;
                 else        // swizzled 16-byte pieces, see a_swz in the kernel
-                    am[(size_t)n * 32 + 8 * ((b >> 3) ^ ((n >> 2) & 3)) + (b & 7)] = 0xbf00;
+                    am[(size_t)n * 32 + 8 * ((b >> 3) ^ ((n >> 2) & 3)) + (b & 7)] =
+                        MF_SPLIT_F16 ? 0xb800 : 0xbf00;
             }
             sq += c * c;
         }
         mask[n] = m;
         v64[n] = v;
-        vt[n] = (float)(h.KB == 16 ? v : 2.0 * v);
+        // score = vt * accumulator + hn; the accumulator is -t * X_SCALE * sum
+        vt[n] = (float)((h.KB == 16 ? v : 2.0 * v) / (double)X_SCALE);
         hn[n] = (float)(0.5 + 0.5 * sq);
         if (n == 0) v_first = v;
         // uniform: every row has the same value and the same weight, so the
@@ -1175,8 +1281,8 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
     }
     // a uniform key (-t * sum) is t / v = t * sqrt(weight) times the score
     h.key_c = 0.0f;
-    h.key_scale =
-        (float)((h.KB == 16 ? 1.0 : 0.5) * std::sqrt((double)__builtin_popcount(mask[0])));
+    h.key_scale = (float)((h.KB == 16 ? 1.0 : 0.5) * (double)X_SCALE *
+                          std::sqrt((double)__builtin_popcount(mask[0])));
     std::memcpy(blob.data(), &h, sizeof(h));
     MF_HIP_CHECK(hipMemcpy(table, blob.data(), (size_t)h.total, hipMemcpyHostToDevice));
     return uniform ? (MF_CODEBOOK_UNIFORM | (min_hd << MF_CODEBOOK_MINHD_SHIFT) |
