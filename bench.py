@@ -247,7 +247,7 @@ def config4(codebook, dev, rank, world, group_backend, n_fovs=400, F=50,
     """BASELINE configs[3] / SURVEY 8d config 4: `n_fovs` synthetic FOVs (seed
     1234 + fov), FOV i on rank i mod world; first the scale-factor loop --
     `iterations` chained OptimizeIteration passes of F random (fov, z)
-    fragments (seed 99 + pass), with optimize_background off and on, each pass
+    fragments (one random stream, seed 99), with optimize_background off and on, each pass
     ending in the packed [F, 2B+N] all-reduce -- then Decode of every FOV with
     the factors the last pass produced (decode.py:107-110), through
     run_fovs_sharded.  FOVs are generated on the device outside the clocks, at
@@ -282,8 +282,8 @@ def config4(codebook, dev, rank, world, group_backend, n_fovs=400, F=50,
            'ranks': world}
     planes = {}
     draws = []
+    rng = np.random.RandomState(99)       # one stream, as run_optimize_chain
     for k in range(iterations):
-        rng = np.random.RandomState(99 + k)
         draws.append([[int(rng.choice(fovs)), int(rng.choice(list(range(z))))]
                       for _ in range(F)])
     for d in draws:

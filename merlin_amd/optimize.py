@@ -152,7 +152,10 @@ class OptimizeIteration(object):
             # optimize.py:43-50.  Every rank must work on the same draw: rank 0
             # draws (from OS entropy when seed is None, like the reference) and
             # the list is broadcast.
-            rng = np.random.RandomState(seed)
+            # (seed may be a RandomState shared by a chain of iterations: the
+            # reference draws every iteration from numpy's one global stream)
+            rng = seed if isinstance(seed, np.random.RandomState) \
+                else np.random.RandomState(seed)
             p['fov_index'] = broadcast_from_rank0([
                 [int(rng.choice(list(fovs))), int(rng.choice(list(range(zCount))))]
                 for _ in range(p['fov_per_iteration'])], group)
@@ -379,20 +382,23 @@ def run_optimize_chain(codebook, imageProvider, fovs, zCount,
     JSON chains them through ``previous_iteration`` (optimize.py:61-62,
     158-165; the reference's test run chains two,
     test/auxiliary_files/test_analysis_parameters.json:17-41): every pass draws
-    its own ``fov_per_iteration`` random (fov, z) fragments (optimize.py:43-50;
-    ``seed + k`` for pass k when a seed is given), shards them over the ranks
-    of ``group`` and ends in the one exchange step.  Returns the list of
+    its own ``fov_per_iteration`` random (fov, z) fragments (optimize.py:43-50)
+    from ONE random stream, as the reference's constructors draw from numpy's
+    global one (``seed``: what ``np.random.seed`` would be given; None = OS
+    entropy), shards them over the ranks of ``group`` and ends in the one
+    exchange step.  Returns the list of
     completed iterations; the last one's get_scale_factors() /
     get_backgrounds() are what Decode uses (decode.py:107-110)."""
     done = []
     prev = None
+    rng = np.random.RandomState(seed)
     for k in range(iterations):
         it = OptimizeIteration(
             codebook, parameters, fovs=fovs, zCount=zCount,
             previousIteration=prev,
             initialScaleFactors=initialScaleFactors if prev is None else None,
             imageProvider=imageProvider, device=device, group=group,
-            seed=None if seed is None else seed + k)
+            seed=rng)
         it.run()
         done.append(it)
         prev = it

@@ -42,8 +42,8 @@ def test_config4_scaled_down_matches_oracle(gpu_device, background):
 
     # the oracle's loop over the same draws
     sf, bg = init.astype(np.float64), np.zeros(16)
+    rng = np.random.RandomState(99)
     for k, it in enumerate(chain):
-        rng = np.random.RandomState(99 + k)
         draw = [[int(rng.choice(list(range(n_fovs)))),
                  int(rng.choice(list(range(Z))))] for _ in range(F)]
         assert it.parameters['fov_index'] == draw
@@ -123,3 +123,50 @@ def test_bench_two_ranks_gloo_one_card(gpu_device):
     assert c4['exchange_own_rows_intact'] is True
     assert c4['decode']['records'] > 0
     assert 'roofline' in out and out['roofline']['frac'] > 0
+
+
+@pytest.mark.parametrize('mode', ['plain_', 'bg_'])
+def test_optimize_chain_matches_reference_trace(gpu_device, mode):
+    """Two chained OptimizeIteration passes on the GPU against the trace the
+    reference's own analysis/optimize.py produced on the same images
+    (tests/golden/g7_optimize_trace.npz): same fragment draws, per-fragment
+    refactors / counts, scale factors, backgrounds and histories.  Counts and
+    the NaN / zero pattern are exact; values agree to the float32 rounding of
+    the pixel magnitudes (the reference's go through BLAS sdot)."""
+    import torch
+    from conftest import GOLDEN_DIR
+    from merlin_amd import optimize
+    g = np.load(os.path.join(GOLDEN_DIR, 'g7_optimize_trace.npz'))
+    g7 = {k: g[k] for k in g.files}
+    imgs = [torch.from_numpy(i).to(gpu_device) for i in g7['images']]
+    hist = sum(optimize.pixel_histogram(d) for d in imgs)
+    init = optimize.initial_scale_factors(optimize.summed_pixel_histogram(hist))
+    assert np.array_equal(init, g7[mode + 'it0_previous_scale_factors'][0])
+    chain = optimize.run_optimize_chain(
+        ArrayCodebook(g7['codebook']), lambda f, z: imgs[f][:, z],
+        list(range(len(imgs))), g7['images'].shape[2], init, 2,
+        {'fov_per_iteration': int(g7['F']), 'optimize_background': mode == 'bg_'},
+        gpu_device, None, seed=int(g7['seed']))
+    for k, it in enumerate(chain):
+        p = mode + 'it{}_'.format(k)
+        assert it.parameters['fov_index'] == g7[p + 'fov_index'].tolist()
+        assert np.array_equal(it._counts, g7[p + 'barcode_counts'])
+        exp = g7[p + 'scale_refactors']
+        assert np.array_equal(np.isnan(it._refactors), np.isnan(exp))
+        assert np.array_equal(it._refactors == 0, exp == 0)
+        np.testing.assert_allclose(it._refactors, exp, rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(it._bg_refactors, g7[p + 'background_refactors'],
+                                   rtol=1e-6, atol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(it.get_scale_factors(), g7[p + 'scale_factors'],
+                                   rtol=1e-6, equal_nan=True)
+        np.testing.assert_allclose(it.get_backgrounds(), g7[p + 'backgrounds'],
+                                   rtol=1e-6, atol=1e-7, equal_nan=True)
+        np.testing.assert_allclose(it.get_scale_factor_history(),
+                                   g7[p + 'scale_factor_history'], rtol=1e-6)
+        assert np.array_equal(it.get_barcode_count_history(),
+                              g7[p + 'barcode_count_history'])
+        # the fragments' barcode tables: as many rows as the reference wrote
+        assert [len(it.barcodes[i]) for i in range(int(g7['F']))] == \
+            g7[p + 'barcodes_written'].tolist()
+    # the bit no barcode uses keeps its initial factor (refactors == 0 -> 1)
+    assert chain[-1].get_scale_factors()[-1] == init[-1]
