@@ -15,7 +15,6 @@ import struct
 from typing import Tuple
 
 import numpy as np
-import torch
 
 _TYPE_SIZES = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 16: 8}
 
@@ -138,6 +137,7 @@ def decoded_image_stack(vol, pinned: bool = True) -> np.ndarray:
     """float32 [Z*3, H, W] in the reference's page order (per z: decoded,
     magnitude, distance; decode.py:202-213) from a DecodedVolume: cast and
     interleaved on the GPU, one device-to-host copy."""
+    import torch
     dec, mag, dist = vol.decoded, vol.magnitudes, vol.distances
     if dec.dim() == 2:
         dec, mag, dist = dec[None], mag[None], dist[None]

@@ -1,8 +1,14 @@
 """Decoded-image writer (merlin_amd/imagewriter.py): the TIFF container on CPU,
-the device-side interleave on the GPU.  The container was also read back with
-tifffile 2021 in the build container (is_imagej, 21 pages, pixel-identical);
-tifffile is not importable where the tests run, so the checks here use the
-module's own reader plus direct inspection of the directory entries."""
+the device-side interleave on the GPU.  tifffile -- what the reference writes
+and reads these files with (core/dataset.py:196-220) -- is not importable where
+the tests run; tests/golden/tiff_decoded_reference.npz (made by
+oracle/make_tiff_golden.py under the build container's tifffile 2021.7.2)
+holds (a) the bytes of a file tifffile wrote for a small stack, with what
+tifffile reads back from it, and (b) the bytes of the file this module's
+writer makes for the same stack, which that script checked WITH tifffile
+(ImageJ hyperstack, slices / frames of the reference's description, pages
+identical, page-by-index read as dataset.py:200-203)."""
+import os
 import struct
 
 import numpy as np
@@ -72,3 +78,50 @@ def test_save_decoded_images(gpu_device, tmp_path):
         assert np.array_equal(pages[3 * z + 1], vol.magnitudes[z].cpu().numpy())
         assert np.array_equal(pages[3 * z + 2],
                               vol.distances[z].cpu().numpy().astype(np.float32))
+
+
+@pytest.fixture(scope='module')
+def tiff_fixture():
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'tiff_decoded_reference.npz'))
+    return {k: g[k] for k in g.files}
+
+
+def _stack(fx):
+    Z = fx['decoded'].shape[0]
+    stack = np.empty((Z * 3,) + fx['decoded'].shape[1:], dtype=np.float32)
+    stack[0::3], stack[1::3], stack[2::3] = fx['decoded'], fx['magnitude'], fx['distance']
+    return stack
+
+
+def test_reader_reads_a_tifffile_written_stack(tiff_fixture, tmp_path):
+    """read_hyperstack on the file tifffile itself wrote: same pages, same
+    ImageDescription as tifffile reads from it."""
+    fx = tiff_fixture
+    path = str(tmp_path / 'ref.tif')
+    open(path, 'wb').write(fx['file_bytes'].tobytes())
+    pages, desc = iw.read_hyperstack(path)
+    assert pages.dtype == np.float32 and np.array_equal(pages, fx['pages'])
+    assert np.array_equal(pages, _stack(fx))
+    assert desc.strip() == str(fx['descriptions'][0]).strip()      # tifffile strips the text
+    # page by index, as DataSet.get_analysis_image does (dataset.py:200-203)
+    assert np.array_equal(pages[1 * 3 + 1], fx['magnitude'][1])
+
+
+def test_writer_output_is_the_file_tifffile_validated(tiff_fixture, tmp_path):
+    """write_hyperstack for the fixture's stack and the reference's metadata
+    dictionary gives, byte for byte, the file that oracle/make_tiff_golden.py
+    opened with tifffile (is_imagej, slices = z, frames = 3, pages equal)."""
+    fx = tiff_fixture
+    Z = fx['decoded'].shape[0]
+    path = str(tmp_path / 'ours.tif')
+    iw.write_hyperstack(path, _stack(fx), iw.analysis_tiff_description(Z, 3))
+    assert open(path, 'rb').read() == fx['our_file_bytes'].tobytes()
+    assert str(fx['our_series_axes']) == 'TZYX'
+    assert fx['our_series_shape'].tolist() == [3, Z] + list(fx['decoded'].shape[1:])
+    # the baseline tags tifffile writes per page are all present in ours
+    raw = fx['our_file_bytes'].tobytes()
+    first = struct.unpack_from('<I', raw, 4)[0]
+    n_tags = struct.unpack_from('<H', raw, first)[0]
+    ours = {struct.unpack_from('<H', raw, first + 2 + 12 * i)[0] for i in range(n_tags)}
+    assert set(fx['first_page_tags'].tolist()) - {305} <= ours      # 305 = Software
