@@ -63,6 +63,8 @@ class Decode(object):
         # depth of the run_fovs pipeline (see there)
         self.decodeAhead = 1
         self.frameLag = 2
+        # worker threads of the decoded-image output (imagewriter.AsyncImageWriter)
+        self.imageWriters = 4
 
     def get_codebook(self):
         return self._codebook
@@ -151,12 +153,6 @@ class Decode(object):
         p = self.parameters
         zpos = zPositions if zPositions is not None \
             else list(range(vol.shape[0]))
-        if p['write_decoded_images'] and self.outputDirectory is not None:
-            from merlin_amd import imagewriter
-            os.makedirs(self.outputDirectory, exist_ok=True)
-            imagewriter.save_decoded_images(
-                os.path.join(self.outputDirectory,
-                             'decoded_{}.tif'.format(fov)), vol)
         if database is not None:
             # decode.py:225-230 then :170-175, on the database's typed table
             database.write_barcodes(
@@ -182,8 +178,26 @@ class Decode(object):
                 p['z_duplicate_xy_pixel_threshold'], zpos)
         return bc
 
-    def _enqueue_decode(self, imageStack, scaleFactors, backgrounds, lbl=None):
-        """Stage 1 of a FOV: decode kernel + labelling, nothing blocks."""
+    def _queue_images(self, vol, fov):
+        """decode.py:165-168, 196-213: decoded_<fov>.tif, written behind the
+        FOV loop (imagewriter.AsyncImageWriter); complete after flush_images(),
+        which run_fov and the end of run_fovs call."""
+        if not self.parameters['write_decoded_images'] \
+                or self.outputDirectory is None or fov is None:
+            return
+        from merlin_amd import imagewriter
+        if getattr(self, '_image_writer', None) is None:
+            os.makedirs(self.outputDirectory, exist_ok=True)
+            self._image_writer = imagewriter.AsyncImageWriter(
+                vol.decoded.device, workers=self.imageWriters)
+        self._image_writer.submit(
+            os.path.join(self.outputDirectory, 'decoded_{}.tif'.format(fov)),
+            vol)
+
+    def _enqueue_decode(self, imageStack, scaleFactors, backgrounds, lbl=None,
+                        fov=None):
+        """Stage 1 of a FOV: decode kernel + labelling (+ the image output of
+        ``fov``), nothing blocks."""
         timing = getattr(self, 'kernel_events', None)
         if timing is not None:
             # measurement hook (bench.py): HIP events around the decode launch
@@ -195,6 +209,7 @@ class Decode(object):
         if timing is not None:
             e1.record()
             timing.append((e0, e1))
+        self._queue_images(vol, fov)
         is3D = bool(self.parameters['decode_3d'])
         if lbl is None:
             lab = self.decoder._label_enqueue(vol, is3D)
@@ -246,11 +261,14 @@ class Decode(object):
         2-D mode labels every plane in one pass and emits the rows in the
         order the reference writes them (plane, barcode index, label order);
         decode_3d labels the volume with 26-connectivity."""
-        vol, lab = self._enqueue_decode(imageStack, scaleFactors, backgrounds)
+        vol, lab = self._enqueue_decode(imageStack, scaleFactors, backgrounds,
+                                        fov=fov)
         pending = self._enqueue_table(vol, lab, typed=database is not None,
                                       wantXY64=globalAligner is not None)
-        return self._finish_fov(pending, vol, fov, globalAligner,
-                                zPositions, database), vol
+        bc = self._finish_fov(pending, vol, fov, globalAligner, zPositions,
+                              database)
+        self.flush_images()
+        return bc, vol
 
     def run_fovs(self, imageStacks, scaleFactors, backgrounds, fovs=None,
                  globalAligner=None, zPositions=None, database=None):
@@ -294,7 +312,7 @@ class Decode(object):
         for k, stack in enumerate(imageStacks):
             fov = k if fovs is None else fovs[k]
             decoded.append(self._enqueue_decode(stack, scaleFactors,
-                                                backgrounds, lbl) + (fov,))
+                                                backgrounds, lbl, fov) + (fov,))
             if len(decoded) > ahead:
                 table(decoded.popleft())
             while len(tabled) > lag:
@@ -304,7 +322,10 @@ class Decode(object):
             while len(tabled) > lag:
                 yield finish(tabled.popleft())
         while tabled:
+            if len(tabled) == 1:
+                self.flush_images()      # every file on disk before the last FOV
             yield finish(tabled.popleft())
+        self.flush_images()
 
     def run_fovs_sharded(self, stackProvider, scaleFactors, backgrounds, fovs,
                          rank=None, world=None, group=None,

@@ -156,3 +156,88 @@ def save_decoded_images(path: str, vol) -> None:
     pages = decoded_image_stack(vol)
     write_hyperstack(path, pages,
                      analysis_tiff_description(pages.shape[0] // 3, 3))
+
+
+class AsyncImageWriter(object):
+    """Decode._save_decoded_images off the critical path of a FOV loop.
+
+    ``submit(path, vol)`` queues, on a stream of its own, the float32 cast +
+    page interleave of the volume's three images into a device staging buffer
+    and its copy into a page-locked host buffer (352 MB for a 7-z 2048 x 2048
+    FOV: 6.4 ms of PCIe), and hands the file write to a worker thread that
+    waits for the copy's event; nothing blocks the caller unless every staging
+    slot is still busy (``slots`` FOVs in flight; file writes release the
+    interpreter lock, so several run side by side).  ``flush()`` returns once
+    every file queued so far is on disk and re-raises a worker's error.  The
+    files are byte-identical to ``save_decoded_images``'s."""
+
+    def __init__(self, device, workers: int = 4, slots: int = None):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        self.device = torch.device(device)
+        self.slots = slots or workers + 1
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.Stream(self.device)
+        self._pool = ThreadPoolExecutor(max_workers=workers)
+        self._free = []          # (device staging, pinned host) of finished writes
+        self._busy = []          # (future, buffers) in submission order
+        self._made = 0
+
+    def _buffers(self, shape):
+        import torch
+        while True:
+            for i, (d, h) in enumerate(self._free):
+                if tuple(d.shape) == tuple(shape):
+                    return self._free.pop(i)
+            if self._made < self.slots:
+                self._free = []                      # other shapes: let them go
+                self._made += 1
+                return (torch.empty(shape, dtype=torch.float32, device=self.device),
+                        torch.empty(shape, dtype=torch.float32, pin_memory=True))
+            fut, bufs = self._busy.pop(0)            # oldest write still running
+            fut.result()
+            self._free.append(bufs)
+
+    def submit(self, path: str, vol) -> None:
+        import torch
+        dec, mag, dist = vol.decoded, vol.magnitudes, vol.distances
+        if dec.dim() == 2:
+            dec, mag, dist = dec[None], mag[None], dist[None]
+        Z, H, W = dec.shape
+        self._reap()
+        stage, host = self._buffers((Z, 3, H, W))
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                stage[:, 0] = dec
+                stage[:, 1] = mag
+                stage[:, 2] = dist
+                host.copy_(stage, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            for t in (dec, mag, dist):
+                t.record_stream(self.stream)
+        meta = analysis_tiff_description(Z, 3)
+
+        def work():
+            done.synchronize()
+            write_hyperstack(path, host.numpy().reshape(Z * 3, H, W), meta)
+
+        self._busy.append((self._pool.submit(work), (stage, host)))
+
+    def _reap(self):
+        while self._busy and self._busy[0][0].done():
+            fut, bufs = self._busy.pop(0)
+            fut.result()
+            self._free.append(bufs)
+
+    def flush(self) -> None:
+        while self._busy:
+            fut, bufs = self._busy.pop(0)
+            fut.result()
+            self._free.append(bufs)
+
+    def close(self) -> None:
+        self.flush()
+        self._pool.shutdown()

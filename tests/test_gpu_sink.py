@@ -165,6 +165,41 @@ def test_decoded_images_written_and_memory_map_accepted(gpu_device, tmp_path):
     assert bc.equals(bc2)
 
 
+def test_run_fovs_writes_images_behind_the_loop(gpu_device, tmp_path):
+    """run_fovs with an output directory: the files are written by worker
+    threads behind the pipeline (more FOVs than staging slots), complete when
+    the generator is exhausted, and byte-identical to the synchronous
+    save_decoded_images of the same volumes; the barcode tables do not
+    change."""
+    import torch
+    from merlin_amd import imagewriter
+    from merlin_amd.decode import Decode
+    cb = load_golden('g2_synth192')['codebook']
+    stacks = [torch.from_numpy(synth_stack(cb, (2, 64, 96), 40, seed=60 + k)).to(gpu_device)
+              for k in range(7)]
+    stacks[3] = torch.zeros_like(stacks[3])
+    sf, bg = np.full(16, 400.0), np.zeros(16)
+    out = tmp_path / 'images'
+    task = Decode(ArrayCodebook(cb), {'crop_width': 2}, device=gpu_device,
+                  outputDirectory=str(out))
+    task.imageWriters = 2                   # 3 staging slots for 7 FOVs
+    fovs = [20 + k for k in range(7)]
+    got = list(task.run_fovs(iter(stacks), sf, bg, fovs=fovs))
+    plain = Decode(ArrayCodebook(cb), {'crop_width': 2}, device=gpu_device)
+    for k, (bc, vol) in enumerate(got):
+        path = out / 'decoded_{}.tif'.format(fovs[k])
+        assert path.exists()
+        ref = tmp_path / 'sync_{}.tif'.format(k)
+        imagewriter.save_decoded_images(str(ref), vol)
+        assert path.read_bytes() == ref.read_bytes()
+        ebc, _ = plain.run_fov(stacks[k], sf, bg, fovs[k])
+        assert bc.equals(ebc)
+    # a second pass over the same task reuses the staging slots
+    got2 = list(task.run_fovs(iter(stacks[:2]), sf, bg, fovs=[90, 91]))
+    assert (out / 'decoded_91.tif').read_bytes() == (out / 'decoded_21.tif').read_bytes()
+    assert len(got2) == 2
+
+
 def test_extraction_follows_in_place_edits(gpu_device):
     """The drop-in decoder keeps the decoded volume on the GPU between
     decode_pixels and the extraction calls; it must never serve a stale copy
