@@ -14,7 +14,6 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 
 namespace {
@@ -368,46 +367,6 @@ __device__ __forceinline__ int block_exclusive_scan(int v)
     return base + inc - v;
 }
 
-// flags of the four items a thread owns: bit k set iff item i0 + k is kept
-__device__ __forceinline__ unsigned assigned_flags(const int16_t *dec, int64_t i0, int64_t n)
-{
-    unsigned f = 0;
-    if (i0 + 3 < n) {
-        // i0 is a multiple of 4: one aligned 8-byte load
-        const ushort4 v = *reinterpret_cast<const ushort4 *>(dec + i0);
-        f = (unsigned)(!(v.x >> 15)) | (unsigned)(!(v.y >> 15)) << 1 |
-            (unsigned)(!(v.z >> 15)) << 2 | (unsigned)(!(v.w >> 15)) << 3;
-    } else {
-        for (int k = 0; k < 4; ++k)
-            if (i0 + k < n && dec[i0 + k] >= 0) f |= 1u << k;
-    }
-    return f;
-}
-
-__device__ __forceinline__ unsigned boundary_flags(const uint32_t *keys, int64_t i0, int64_t n)
-{
-    unsigned f = 0;
-    uint32_t prev = i0 > 0 && i0 < n ? keys[i0 - 1] : 0u;
-    for (int k = 0; k < 4; ++k) {
-        if (i0 + k >= n) break;
-        const uint32_t cur = keys[i0 + k];
-        if (i0 + k == 0 || cur != prev) f |= 1u << k;
-        prev = cur;
-    }
-    return f;
-}
-
-template <bool BOUNDARY>
-__global__ void __launch_bounds__(NT)
-chunk_count(const int16_t *__restrict__ dec, const uint32_t *__restrict__ keys, int64_t n,
-            int32_t *__restrict__ counts)
-{
-    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
-    const unsigned f = BOUNDARY ? boundary_flags(keys, i0, n) : assigned_flags(dec, i0, n);
-    const int total = block_reduce_sum(__popc(f));
-    if (threadIdx.x == 0) counts[blockIdx.x] = total;
-}
-
 // in-place exclusive scan of the chunk counts by ONE block; thread t owns a
 // contiguous slice of `per` counts (a multiple of 4, read as independent
 // 16-byte loads: the kernel is pure latency)
@@ -454,78 +413,9 @@ chunk_scan(int32_t *counts, int n_chunks, unsigned long long *total)
     if (total && hi == n_chunks && lo < n_chunks) *total = (unsigned long long)run;
 }
 
-// assigned pixels in raster order with their component root as sort key
-__global__ void __launch_bounds__(NT)
-emit_assigned(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t n,
-              const int32_t *__restrict__ offsets, int64_t cap, int32_t *__restrict__ pix,
-              uint32_t *__restrict__ keys)
-{
-    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
-    // a pixel is assigned iff its label is >= 0 (mf_label_components): the four
-    // labels come as one 16-byte load and the barcodes need not be read again
-    int lab[4] = {-1, -1, -1, -1};
-    if (i0 + 3 < n) {
-        const int4 v = *reinterpret_cast<const int4 *>(L + i0);
-        lab[0] = v.x; lab[1] = v.y; lab[2] = v.z; lab[3] = v.w;
-    } else {
-        for (int k = 0; k < 4; ++k)
-            if (i0 + k < n) lab[k] = L[i0 + k];
-    }
-    (void)dec;
-    unsigned f = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) f |= (unsigned)(lab[k] >= 0) << k;
-    int pos = offsets[blockIdx.x] + block_exclusive_scan(__popc(f));
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (f >> k & 1u) {
-            if (pos < cap) {           // cap: the caller's n_pixels sized the lists
-                pix[pos] = (int32_t)(i0 + k);
-                keys[pos] = (uint32_t)lab[k];
-            }
-            ++pos;
-        }
-}
-
-// first entry of every region in the root-sorted pixel list
-__global__ void __launch_bounds__(NT)
-emit_boundaries(const uint32_t *__restrict__ keys, int64_t n,
-                const int32_t *__restrict__ offsets, int64_t cap, int32_t *__restrict__ starts)
-{
-    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
-    const unsigned f = boundary_flags(keys, i0, n);
-    int pos = offsets[blockIdx.x] + block_exclusive_scan(__popc(f));
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (f >> k & 1u) {
-            if (pos < cap) starts[pos] = (int32_t)(i0 + k);
-            ++pos;
-        }
-}
-
-// Regions arrive ordered by root.  The reference emits them by z plane (2-D
-// mode), then barcode, then label order (= root order): key = plane * 32768 +
-// barcode, sorted stably.  In 2-D mode the plane is root / plane_px.
-__global__ void __launch_bounds__(NT)
-region_keys(const uint32_t *__restrict__ roots_sorted, const int32_t *__restrict__ offsets,
-            const int16_t *__restrict__ dec, int64_t n_reg, int64_t n_pix, int plane_px,
-            int conn3d, uint32_t *__restrict__ keys, int64_t *__restrict__ span)
-{
-    const int64_t j = (int64_t)blockIdx.x * NT + threadIdx.x;
-    if (j >= n_reg) return;
-    const int32_t lo = offsets[j];
-    const int64_t hi = j + 1 < n_reg ? offsets[j + 1] : n_pix;
-    const uint32_t root = roots_sorted[lo];
-    const uint32_t grp = conn3d ? 0u : root / (uint32_t)plane_px;
-    keys[j] = grp * 32768u + (uint32_t)dec[root];
-    // the sort carries the region's span in the pixel list along, so the
-    // statistics kernel starts from one load instead of a chain of three
-    span[j] = (int64_t)lo | (hi << 32);
-}
-
 struct StatsArgs {
-    const int32_t *pix;      // sorted by root, raster order inside a region
-    const int64_t *span;     // [n_regions] first | one-past-last << 32 of row r's pixels
+    const int32_t *pix;      // grouped by region in row order, raster order inside a region
+    const int32_t *start;    // [n_regions + 1] where row r's pixels begin in pix
     int64_t tr_p;
     int64_t n_pix, n_reg;
     const int16_t *dec;
@@ -609,8 +499,7 @@ region_stats(const StatsArgs a)
     StageGroup &st = stage[threadIdx.x / RSUB];
     const bool valid = r < a.n_reg;
     if (!valid) r = a.n_reg - 1;          // keep whole groups alive
-    const int64_t sp_ = a.span[r];
-    const int i0 = (int)(sp_ & 0xffffffffll), i1 = (int)(sp_ >> 32);
+    const int i0 = a.start[r], i1 = a.start[r + 1];
     const int n = i1 - i0;
     const int plane = a.H * a.W;
     const int first = a.pix[i0];
@@ -795,42 +684,472 @@ region_stats(const StatsArgs a)
     }
 }
 
-// Onesweep with 9-bit digits: a pass has a fixed cost of tens of us here
-// almost regardless of the element count, so the number of passes is what
-// matters -- 3 instead of 4 for the <= 27-bit pixel keys, 2 instead of 3 for
-// the <= 18-bit region keys.  (rocPRIM's default for ~2e5 elements would be a
-// block sort plus ~18 merge launches: the 4096 limit forces onesweep.)
-#ifndef MF_RADIX_BITS
-#define MF_RADIX_BITS 9
-#endif
-// Sort blocks of 512 threads x 12 items.  Per pass over the 6.9 M (root, pixel)
-// pairs of a 7-z FOV with the GPU to itself: 512 x 8: 73 us, 512 x 12: 65,
-// 512 x 16: 71, 256 x 16: 103, 1024 x 6: 55, 1024 x 8: 51, 1024 x 10 / 12: 72-74
-// (dev/time_region_variants.sh).  What counts is the FOV pipeline, where the sort
-// runs beside the next FOV's decode kernel and a block has to fit into the LDS
-// and wave slots that kernel leaves free: 512 x 8: 1.873 ms per FOV, 512 x 10:
-// 1.848, 512 x 12: 1.845, 256 x 16: 1.90, 256 x 24: 1.87, and 2.00-2.06 for every
-// shape with 64 KB of LDS per block (1024 x 6 / 8, 512 x 16) (dev/pipedepth.py).
-#ifndef MF_SORT_BLOCK
-#define MF_SORT_BLOCK (1 << MF_RADIX_BITS)
-#endif
-#ifndef MF_SORT_IPT
-#define MF_SORT_IPT 12
-#endif
-using Onesweep9 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<MF_SORT_BLOCK, MF_SORT_IPT>,
-                                                      rocprim::kernel_config<MF_SORT_BLOCK, MF_SORT_IPT>,
-                                                      MF_RADIX_BITS,
-                                                      rocprim::block_radix_rank_algorithm::match>;
-using PixelSortConfig =
-    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, Onesweep9, 4096>;
-using RegionSortConfig = PixelSortConfig;
+// ---- horizontal runs ---------------------------------------------------------
+// A run is a maximal horizontal sequence of pixels with the same barcode >= 0.
+// Horizontally adjacent equal barcodes are always connected, so a run lies in
+// ONE region, a region is a set of runs, and its first pixel in raster order
+// (the root the labelling left in L) is the first pixel of one of its runs.
+// The table is therefore prepared on runs (one per ~5 assigned pixels), not on
+// pixels: the runs come out of the barcode image in raster order (count / scan /
+// emit over 1024-pixel chunks: starts, ends and region roots in one go), are
+// keyed with their region's place in the reference's row order and sorted
+// (stable: a region's runs stay in raster order), and are then expanded back
+// into the pixel list region_stats walks.
+
+// flags of the four pixels a thread owns: bit k = run start, bit 4 + k = run
+// end, bit 8 + k = region root (run start whose label is its own index)
+__device__ __forceinline__ unsigned run_flags(const int16_t *__restrict__ dec,
+                                              const int32_t *__restrict__ L, int64_t i0,
+                                              int64_t n, int W)
+{
+    if (i0 >= n) return 0u;
+    int c[6];                       // c[0] = left neighbour, c[5] = right neighbour
+    if (i0 + 3 < n) {
+        const ushort4 v = *reinterpret_cast<const ushort4 *>(dec + i0);
+        c[1] = (int16_t)v.x; c[2] = (int16_t)v.y; c[3] = (int16_t)v.z; c[4] = (int16_t)v.w;
+    } else {
+        for (int k = 0; k < 4; ++k) c[1 + k] = i0 + k < n ? (int)dec[i0 + k] : -1;
+    }
+    if ((c[1] & c[2] & c[3] & c[4]) < 0) return 0u;          // four unassigned pixels
+    c[0] = i0 > 0 ? (int)dec[i0 - 1] : -1;
+    c[5] = i0 + 4 < n ? (int)dec[i0 + 4] : -1;
+    int x = (int)(i0 % W);
+    unsigned f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (c[1 + k] >= 0) {
+            const bool start = x == 0 || c[k] != c[1 + k];
+            const bool end = x == W - 1 || c[2 + k] != c[1 + k];
+            if (start) {
+                f |= 1u << k;
+                if (L[i0 + k] == (int32_t)(i0 + k)) f |= 0x100u << k;
+            }
+            if (end) f |= 0x10u << k;
+        }
+        if (++x == W) x = 0;
+    }
+    return f;
+}
+
+// three counts per chunk packed into one 64-bit word (21 bits each)
+__device__ __forceinline__ unsigned long long pack3(unsigned f)
+{
+    return (unsigned long long)__popc(f & 0xfu) | (unsigned long long)__popc(f & 0xf0u) << 21 |
+           (unsigned long long)__popc(f & 0xf00u) << 42;
+}
+
+__global__ void __launch_bounds__(NT)
+run_count(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t n, int W,
+          int n_chunks, int32_t *__restrict__ counts)
+{
+    __shared__ unsigned long long s_part[NT / 64];
+    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
+    unsigned long long v = pack3(run_flags(dec, L, i0, n, W));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) t += s_part[w];
+        counts[blockIdx.x] = (int32_t)(t & 0x1fffffu);
+        counts[n_chunks + blockIdx.x] = (int32_t)(t >> 21 & 0x1fffffu);
+        counts[2 * n_chunks + blockIdx.x] = (int32_t)(t >> 42);
+    }
+}
+
+// chunk_scan over `arrays` count arrays of n_chunks entries laid out one after
+// the other, one block each; totals[k] receives array k's sum
+__global__ void __launch_bounds__(SCAN_NT)
+chunk_scan_multi(int32_t *counts, int n_chunks, unsigned long long *totals)
+{
+    int32_t *c = counts + (size_t)blockIdx.x * n_chunks;
+    __shared__ int s_wave[SCAN_NT / 64];
+    const int per = ((n_chunks + SCAN_NT - 1) / SCAN_NT + 3) & ~3;
+    const int lo = min(n_chunks, (int)threadIdx.x * per), hi = min(n_chunks, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += c[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int j = 0; j < w; ++j) base += s_wave[j];
+    int run = base + inc - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int v = c[i];
+        c[i] = run;
+        run += v;
+    }
+    if (totals && hi == n_chunks && lo < n_chunks) totals[blockIdx.x] = (unsigned long long)run;
+    if (totals && n_chunks == 0 && threadIdx.x == 0) totals[blockIdx.x] = 0ull;
+}
+
+// Runs in raster order: first pixel, last pixel and region root of run i; the
+// regions' roots in raster (= label) order with the key of the reference's row
+// order: z plane (2-D mode), then barcode.
+__global__ void __launch_bounds__(NT)
+run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t n, int W,
+         int n_chunks, const int32_t *__restrict__ offsets, int64_t cap_runs, int64_t cap_regions,
+         int plane_px, int conn3d, int32_t *__restrict__ run_start, int32_t *__restrict__ run_end,
+         int32_t *__restrict__ run_root, uint32_t *__restrict__ reg_root,
+         uint32_t *__restrict__ reg_key)
+{
+    __shared__ unsigned long long s_wave[NT / 64];
+    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
+    const unsigned f = run_flags(dec, L, i0, n, W);
+    const unsigned long long mine = pack3(f);
+    // exclusive prefix of the packed counts over the block's threads
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0;
+#pragma unroll
+    for (int j = 0; j < NT / 64; ++j) base += j < w ? s_wave[j] : 0ull;
+    const unsigned long long ex = base + inc - mine;
+    int64_t ps = (int64_t)offsets[blockIdx.x] + (int64_t)(ex & 0x1fffffu);
+    int64_t pe = (int64_t)offsets[n_chunks + blockIdx.x] + (int64_t)(ex >> 21 & 0x1fffffu);
+    int64_t pr = (int64_t)offsets[2 * n_chunks + blockIdx.x] + (int64_t)(ex >> 42);
+    if (!f) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int32_t p = (int32_t)(i0 + k);
+        if (f >> k & 1u) {
+            const bool root = f >> (8 + k) & 1u;
+            if (ps < cap_runs) {
+                run_start[ps] = p;
+                run_root[ps] = root ? p : L[p];
+            }
+            ++ps;
+            if (root) {
+                if (pr < cap_regions) {
+                    reg_root[pr] = (uint32_t)p;
+                    const uint32_t grp = conn3d ? 0u : (uint32_t)p / (uint32_t)plane_px;
+                    reg_key[pr] = grp * 32768u + (uint32_t)dec[p];
+                }
+                ++pr;
+            }
+        }
+        if (f >> (4 + k) & 1u) {
+            if (pe < cap_runs) run_end[pe] = p;
+            ++pe;
+        }
+    }
+}
+
+// ---- stable least-significant-digit radix sort -------------------------------
+// Keys of `bits` significant bits, digits of up to 10 bits, one pass per digit:
+// a histogram of every 4096-item tile, an exclusive scan of the [tile][digit]
+// counts down the tiles, and a scatter that ranks a tile's items among the
+// items of equal digit in index order (wave w owns items [1024 w, 1024 w + 1024)
+// of the tile, taken 64 consecutive items at a time; equal digits inside a step
+// are found with one ballot per digit bit).  Sizes here are 2e5 - 2e6 items:
+// what matters is the number of passes and launches, not the last GB/s.
+constexpr int RS_TILE = 4096;
+constexpr int RS_IPT = RS_TILE / NT;          // 16
+constexpr int RS_MAX_BINS = 1024;
+constexpr int RS_SEGS = 16;                   // row segments of the count scan
+
+__device__ __forceinline__ int64_t rs_count(const unsigned long long *n_dev, int64_t n_host)
+{
+    if (!n_dev) return n_host;
+    const int64_t v = (int64_t)*n_dev;
+    return v < n_host ? v : n_host;
+}
+
+__global__ void __launch_bounds__(NT)
+rs_hist(const uint32_t *__restrict__ keys, const unsigned long long *n_dev, int64_t n_host,
+        int shift, int bins, int32_t *__restrict__ cnt)
+{
+    __shared__ int hist[RS_MAX_BINS];
+    const int64_t n = rs_count(n_dev, n_host);
+    const int64_t t0 = (int64_t)blockIdx.x * RS_TILE;
+    if (t0 >= n) return;
+    for (int b = threadIdx.x; b < bins; b += NT) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const int64_t i = t0 + k * NT + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & (uint32_t)(bins - 1)], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += NT) cnt[(size_t)blockIdx.x * bins + b] = hist[b];
+}
+
+// exclusive scan of cnt[tile][digit] down the tiles, per digit; totals[digit]
+// = items with that digit.  A block owns 64 digits; its 16 waves each take a
+// contiguous segment of the tiles.
+__global__ void __launch_bounds__(64 * RS_SEGS)
+rs_scan(int32_t *__restrict__ cnt, const unsigned long long *n_dev, int64_t n_host, int bins,
+        int32_t *__restrict__ totals)
+{
+    __shared__ int seg_sum[RS_SEGS][64];
+    const int64_t n = rs_count(n_dev, n_host);
+    const int rows = (int)((n + RS_TILE - 1) / RS_TILE);
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + lane;
+    const bool live = bin < bins;
+    const int per = (rows + RS_SEGS - 1) / RS_SEGS;
+    const int lo = min(rows, seg * per), hi = min(rows, lo + per);
+    int sum = 0;
+    if (live)
+        for (int r = lo; r < hi; ++r) sum += cnt[(size_t)r * bins + bin];
+    seg_sum[seg][lane] = sum;
+    __syncthreads();
+    int run = 0, total = 0;
+#pragma unroll
+    for (int s = 0; s < RS_SEGS; ++s) {
+        const int v = seg_sum[s][lane];
+        if (s < seg) run += v;
+        total += v;
+    }
+    if (live) {
+        for (int r = lo; r < hi; ++r) {
+            const size_t at = (size_t)r * bins + bin;
+            const int v = cnt[at];
+            cnt[at] = run;
+            run += v;
+        }
+        if (seg == 0) totals[bin] = total;
+    }
+}
+
+template <typename V>
+__global__ void __launch_bounds__(NT)
+rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
+           const unsigned long long *n_dev, int64_t n_host, int shift, int bins,
+           const int32_t *__restrict__ cnt, const int32_t *__restrict__ totals,
+           uint32_t *__restrict__ keys_out, V *__restrict__ vals_out)
+{
+    __shared__ int cw[NT / 64][RS_MAX_BINS];      // per wave: running count, then position
+    __shared__ int s_wave[NT / 64];
+    const int64_t n = rs_count(n_dev, n_host);
+    const int64_t t0 = (int64_t)blockIdx.x * RS_TILE;
+    if (t0 >= n) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t mask = (uint32_t)(bins - 1);
+    int nbits = 0;
+    while ((1 << nbits) < bins) ++nbits;
+    for (int b = threadIdx.x; b < (NT / 64) * RS_MAX_BINS; b += NT) (&cw[0][0])[b] = 0;
+    __syncthreads();
+
+    uint32_t key[RS_IPT];
+    int rank[RS_IPT];
+    const int64_t w0 = t0 + (int64_t)w * (RS_TILE / (NT / 64));
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const int64_t i = w0 + k * 64 + lane;
+        const bool valid = i < n;
+        key[k] = valid ? keys_in[i] : 0u;
+        const uint32_t d = (key[k] >> shift) & mask;
+        // lanes of this step with the same digit
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const unsigned long long vote = __ballot((d >> b) & 1u);
+            peers &= (d >> b) & 1u ? vote : ~vote;
+        }
+        const unsigned long long below = peers & ((1ull << lane) - 1ull);
+        int r = 0;
+        if (valid) {
+            r = cw[w][d] + __popcll(below);
+            rank[k] = r;
+        } else {
+            rank[k] = 0;
+        }
+        group_sync();                       // every lane has read the count
+        if (valid && below == 0ull) cw[w][d] = r + __popcll(peers);   // the group's first lane
+        group_sync();
+    }
+    __syncthreads();
+    // digit bases: items of smaller digits, plus this digit's items in earlier
+    // tiles, plus this digit's items in the tile's earlier waves
+    {
+        // exclusive scan of totals over the digits: thread t owns 4 consecutive
+        const int per = RS_MAX_BINS / NT;             // 4
+        int tv[RS_MAX_BINS / NT];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            const int b = threadIdx.x * per + j;
+            tv[j] = b < bins ? totals[b] : 0;
+            sum += tv[j];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_wave[w] = inc;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < NT / 64; ++j) base += j < w ? s_wave[j] : 0;
+        int run = base + inc - sum;
+#pragma unroll
+        for (int j = 0; j < per; ++j) {
+            const int b = threadIdx.x * per + j;
+            if (b < bins) {
+                int pos = run + cnt[(size_t)blockIdx.x * bins + b];
+#pragma unroll
+                for (int ww = 0; ww < NT / 64; ++ww) {
+                    const int c = cw[ww][b];
+                    cw[ww][b] = pos;
+                    pos += c;
+                }
+            }
+            run += tv[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const int64_t i = w0 + k * 64 + lane;
+        if (i < n) {
+            const uint32_t d = (key[k] >> shift) & mask;
+            const int64_t dst = (int64_t)cw[w][d] + rank[k];
+            keys_out[dst] = key[k];
+            vals_out[dst] = vals_in[i];
+        }
+    }
+}
+
+struct RadixPlan {
+    int passes, digit_bits[4];
+};
+
+inline RadixPlan radix_plan(int bits)
+{
+    RadixPlan p;
+    if (bits < 1) bits = 1;
+    p.passes = (bits + 9) / 10;
+    const int per = (bits + p.passes - 1) / p.passes;
+    int left = bits;
+    for (int k = 0; k < p.passes; ++k) {
+        p.digit_bits[k] = left < per ? left : per;
+        left -= p.digit_bits[k];
+    }
+    return p;
+}
+
+// Sorts (keys, vals) of n items (n = min(*n_dev, n_host) when n_dev is given;
+// the grid is sized for n_host).  Returns 0 when the result is in the `a`
+// buffers, 1 when it is in the `b` buffers.
+template <typename V>
+int radix_sort(uint32_t *keys_a, uint32_t *keys_b, V *vals_a, V *vals_b,
+               const unsigned long long *n_dev, int64_t n_host, int bits, int32_t *cnt,
+               int32_t *totals, hipStream_t s)
+{
+    const RadixPlan p = radix_plan(bits);
+    const unsigned tiles = (unsigned)((n_host + RS_TILE - 1) / RS_TILE);
+    if (tiles == 0) return 0;
+    int shift = 0, where = 0;
+    for (int k = 0; k < p.passes; ++k) {
+        const int bins = 1 << p.digit_bits[k];
+        const uint32_t *ki = where ? keys_b : keys_a;
+        uint32_t *ko = where ? keys_a : keys_b;
+        const V *vi = where ? vals_b : vals_a;
+        V *vo = where ? vals_a : vals_b;
+        hipLaunchKernelGGL(rs_hist, dim3(tiles), dim3(NT), 0, s, ki, n_dev, n_host, shift, bins, cnt);
+        hipLaunchKernelGGL(rs_scan, dim3((unsigned)((bins + 63) / 64)), dim3(64 * RS_SEGS), 0, s, cnt,
+                           n_dev, n_host, bins, totals);
+        hipLaunchKernelGGL(rs_scatter<V>, dim3(tiles), dim3(NT), 0, s, ki, vi, n_dev, n_host, shift,
+                           bins, cnt, totals, ko, vo);
+        shift += p.digit_bits[k];
+        where ^= 1;
+    }
+    return where;
+}
+
+// place of every region in the reference's row order, written at its root
+__global__ void __launch_bounds__(NT)
+region_ranks(const uint32_t *__restrict__ roots_sorted, int64_t n_reg, int64_t n_pix,
+             int32_t *__restrict__ aux, int32_t *__restrict__ reg_start)
+{
+    const int64_t e = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (e == 0) reg_start[n_reg] = (int32_t)n_pix;
+    if (e < n_reg) aux[roots_sorted[e]] = (int32_t)e;
+}
+
+// sort key (the region's place) and payload (first pixel | length << 32) of a run
+__global__ void __launch_bounds__(NT)
+run_keys(const int32_t *__restrict__ run_start, const int32_t *__restrict__ run_end,
+         const int32_t *__restrict__ run_root, const int32_t *__restrict__ aux,
+         const unsigned long long *n_dev, int64_t cap, uint32_t *__restrict__ keys,
+         unsigned long long *__restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= rs_count(n_dev, cap)) return;
+    const int32_t s = run_start[i];
+    keys[i] = (uint32_t)aux[run_root[i]];
+    vals[i] = (unsigned long long)(uint32_t)s |
+              (unsigned long long)(uint32_t)(run_end[i] - s + 1) << 32;
+}
+
+// pixels per 1024-run chunk of the sorted runs
+__global__ void __launch_bounds__(NT)
+run_len_count(const unsigned long long *__restrict__ vals, const unsigned long long *n_dev,
+              int64_t cap, int32_t *__restrict__ counts)
+{
+    const int64_t n = rs_count(n_dev, cap);
+    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n) sum += (int)(vals[i0 + k] >> 32);
+    const int total = block_reduce_sum(sum);
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+// the sorted runs spelled out as pixels, and where every region's pixels begin
+__global__ void __launch_bounds__(NT)
+run_expand(const uint32_t *__restrict__ keys, const unsigned long long *__restrict__ vals,
+           const unsigned long long *n_dev, int64_t cap, const int32_t *__restrict__ offsets,
+           int64_t n_pix, int32_t *__restrict__ pix, int32_t *__restrict__ reg_start)
+{
+    const int64_t n = rs_count(n_dev, cap);
+    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
+    unsigned long long v[4];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = i0 + k < n ? vals[i0 + k] : 0ull;
+        sum += (int)(v[k] >> 32);
+    }
+    int64_t pos = (int64_t)offsets[blockIdx.x] + block_exclusive_scan(sum);
+    uint32_t prev = i0 > 0 && i0 < n ? keys[i0 - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k >= n) break;
+        const uint32_t key = keys[i0 + k];
+        if (i0 + k == 0 || key != prev) reg_start[key] = (int32_t)pos;
+        prev = key;
+        const int32_t first = (int32_t)(uint32_t)v[k];
+        const int len = (int)(v[k] >> 32);
+        for (int t = 0; t < len; ++t)
+            if (pos + t < n_pix) pix[pos + t] = first + t;
+        pos += len;
+    }
+}
 
 // workspace carve-up shared by the size query and the call
 struct Plan {
-    size_t keys_a, keys_b, pix_a, pix_b, offsets, rkeys_a, rkeys_b, ridx_a, ridx_b, chunks, temp,
-        temp_bytes, total;
-    int vol_chunks, pix_chunks;
-    int root_bits, region_key_bits;
+    size_t run_start, run_end, run_root, keys_a, keys_b, vals_a, vals_b, reg_root_a, reg_root_b,
+        reg_key_a, reg_key_b, reg_start, aux, chunks, totals, sort_cnt, sort_totals, total;
+    int vol_chunks, run_chunks;
+    int region_key_bits, rank_bits;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -838,44 +1157,41 @@ inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
 {
     const int64_t vol = (int64_t)Z * H * W;
-    int rb = 1;
-    while (((int64_t)1 << rb) < vol) ++rb;
-    pl.root_bits = rb;
     int zb = 0;
     while ((1 << zb) < Z) ++zb;
     pl.region_key_bits = 15 + zb;      // barcode < 32768
-    if (pl.region_key_bits > 32)
+    if (pl.region_key_bits > 30)
         return mf::fail(MF_EUNSUPPORTED, "region key needs %d bits", pl.region_key_bits);
+    int rb = 1;
+    while (((int64_t)1 << rb) < n_reg) ++rb;
+    pl.rank_bits = rb;
 
+    // a run has at least one pixel: n_pix bounds the number of runs
     const size_t np = (size_t)(n_pix > 0 ? n_pix : 1), nr = (size_t)(n_reg > 0 ? n_reg : 1);
-    size_t t2 = 0, t4 = 0;
-    // size queries (null temp storage): no work is enqueued
-    hipError_t e;
-    e = rocprim::radix_sort_pairs<PixelSortConfig>(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                  (int32_t *)nullptr, (int32_t *)nullptr, np, 0u,
-                                  (unsigned)pl.root_bits);
-    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
-    e = rocprim::radix_sort_pairs<RegionSortConfig>(nullptr, t4, (uint32_t *)nullptr,
-                                                    (uint32_t *)nullptr, (int64_t *)nullptr,
-                                                    (int64_t *)nullptr, nr, 0u,
-                                                    (unsigned)pl.region_key_bits);
-    if (e != hipSuccess) return mf::fail(MF_EHIP, "rocprim::radix_sort size query: %s", hipGetErrorString(e));
-    pl.temp_bytes = t2 > t4 ? t2 : t4;
     pl.vol_chunks = (int)((vol + CHUNK - 1) / CHUNK);
-    pl.pix_chunks = (int)((np + CHUNK - 1) / CHUNK);
+    pl.run_chunks = (int)((np + CHUNK - 1) / CHUNK);
+    const size_t tiles = (np + RS_TILE - 1) / RS_TILE;
 
     size_t off = 0;
+    pl.run_start = off; off += align_up(np * 4);      // later: the pixel list
+    pl.run_end = off; off += align_up(np * 4);
+    pl.run_root = off; off += align_up(np * 4);
     pl.keys_a = off; off += align_up(np * 4);
     pl.keys_b = off; off += align_up(np * 4);
-    pl.pix_a = off; off += align_up(np * 4);
-    pl.pix_b = off; off += align_up(np * 4);
-    pl.offsets = off; off += align_up((nr + 1) * 4);
-    pl.rkeys_a = off; off += align_up(nr * 4);
-    pl.rkeys_b = off; off += align_up(nr * 4);
-    pl.ridx_a = off; off += align_up(nr * 8);
-    pl.ridx_b = off; off += align_up(nr * 8);
-    pl.chunks = off; off += align_up((size_t)pl.vol_chunks * 4);
-    pl.temp = off; off += align_up(pl.temp_bytes);
+    pl.vals_a = off; off += align_up(np * 8);
+    pl.vals_b = off; off += align_up(np * 8);
+    pl.reg_root_a = off; off += align_up(nr * 4);
+    pl.reg_root_b = off; off += align_up(nr * 4);
+    pl.reg_key_a = off; off += align_up(nr * 4);
+    pl.reg_key_b = off; off += align_up(nr * 4);
+    pl.reg_start = off; off += align_up((nr + 1) * 4);
+    pl.aux = off; off += align_up((size_t)vol * 4);
+    const size_t n_chunk_ints = (size_t)3 * pl.vol_chunks > (size_t)pl.run_chunks
+                                    ? (size_t)3 * pl.vol_chunks : (size_t)pl.run_chunks;
+    pl.chunks = off; off += align_up(n_chunk_ints * 4);
+    pl.totals = off; off += align_up(4 * 8);
+    pl.sort_cnt = off; off += align_up(tiles * RS_MAX_BINS * 4);
+    pl.sort_totals = off; off += align_up(RS_MAX_BINS * 4);
     pl.total = off;
     return MF_OK;
 }
@@ -1288,50 +1604,57 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
                         (long long)pl.total);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    int32_t *run_start = reinterpret_cast<int32_t *>(ws + pl.run_start);
+    int32_t *run_end = reinterpret_cast<int32_t *>(ws + pl.run_end);
+    int32_t *run_root = reinterpret_cast<int32_t *>(ws + pl.run_root);
     uint32_t *keys_a = reinterpret_cast<uint32_t *>(ws + pl.keys_a);
     uint32_t *keys_b = reinterpret_cast<uint32_t *>(ws + pl.keys_b);
-    int32_t *pix_a = reinterpret_cast<int32_t *>(ws + pl.pix_a);
-    int32_t *pix_b = reinterpret_cast<int32_t *>(ws + pl.pix_b);
-    int32_t *offsets = reinterpret_cast<int32_t *>(ws + pl.offsets);
-    uint32_t *rkeys_a = reinterpret_cast<uint32_t *>(ws + pl.rkeys_a);
-    uint32_t *rkeys_b = reinterpret_cast<uint32_t *>(ws + pl.rkeys_b);
-    int64_t *ridx_a = reinterpret_cast<int64_t *>(ws + pl.ridx_a);
-    int64_t *ridx_b = reinterpret_cast<int64_t *>(ws + pl.ridx_b);
+    unsigned long long *vals_a = reinterpret_cast<unsigned long long *>(ws + pl.vals_a);
+    unsigned long long *vals_b = reinterpret_cast<unsigned long long *>(ws + pl.vals_b);
+    uint32_t *reg_root_a = reinterpret_cast<uint32_t *>(ws + pl.reg_root_a);
+    uint32_t *reg_root_b = reinterpret_cast<uint32_t *>(ws + pl.reg_root_b);
+    uint32_t *reg_key_a = reinterpret_cast<uint32_t *>(ws + pl.reg_key_a);
+    uint32_t *reg_key_b = reinterpret_cast<uint32_t *>(ws + pl.reg_key_b);
+    int32_t *reg_start = reinterpret_cast<int32_t *>(ws + pl.reg_start);
+    int32_t *aux = reinterpret_cast<int32_t *>(ws + pl.aux);
     int32_t *chunks = reinterpret_cast<int32_t *>(ws + pl.chunks);
-    void *temp = ws + pl.temp;
-    size_t tb = pl.temp_bytes;
+    unsigned long long *totals = reinterpret_cast<unsigned long long *>(ws + pl.totals);
+    int32_t *sort_cnt = reinterpret_cast<int32_t *>(ws + pl.sort_cnt);
+    int32_t *sort_totals = reinterpret_cast<int32_t *>(ws + pl.sort_totals);
+    const unsigned long long *n_runs = totals;        // device-side count of the runs
 
-    // 1. assigned pixels in raster order, keyed by their component root
-    hipLaunchKernelGGL(chunk_count<false>, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded,
-                       (const uint32_t *)nullptr, vol, chunks);
-    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks,
+    // 1. horizontal runs in raster order (first pixel, last pixel, region root)
+    //    and the regions' roots in label order with their (plane, barcode) key
+    hipLaunchKernelGGL(run_count, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol, W,
+                       pl.vol_chunks, chunks);
+    hipLaunchKernelGGL(chunk_scan_multi, dim3(3), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks, totals);
+    hipLaunchKernelGGL(run_emit, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol, W,
+                       pl.vol_chunks, chunks, n_pixels, n_regions, H * W, conn3d, run_start, run_end,
+                       run_root, reg_root_a, reg_key_a);
+    // 2. the reference's row order of the regions: (plane, barcode), label order
+    //    inside (the sort is stable); every region's place goes to its root
+    const int rw = radix_sort<uint32_t>(reg_key_a, reg_key_b, reg_root_a, reg_root_b, nullptr,
+                                        n_regions, pl.region_key_bits, sort_cnt, sort_totals, s);
+    hipLaunchKernelGGL(region_ranks, dim3((unsigned)((n_regions + NT - 1) / NT)), dim3(NT), 0, s,
+                       rw ? reg_root_b : reg_root_a, n_regions, n_pixels, aux, reg_start);
+    // 3. runs keyed by their region's place, sorted (a region's runs stay in
+    //    raster order), spelled out as pixels
+    hipLaunchKernelGGL(run_keys, dim3((unsigned)((n_pixels + NT - 1) / NT)), dim3(NT), 0, s, run_start,
+                       run_end, run_root, aux, n_runs, n_pixels, keys_a, vals_a);
+    const int pw = radix_sort<unsigned long long>(keys_a, keys_b, vals_a, vals_b, n_runs, n_pixels,
+                                                  pl.rank_bits, sort_cnt, sort_totals, s);
+    const uint32_t *skeys = pw ? keys_b : keys_a;
+    const unsigned long long *svals = pw ? vals_b : vals_a;
+    int32_t *pix = run_start;                         // the runs' own arrays are free now
+    hipLaunchKernelGGL(run_len_count, dim3(pl.run_chunks), dim3(NT), 0, s, svals, n_runs, n_pixels,
+                       chunks);
+    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.run_chunks,
                        (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(emit_assigned, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol,
-                       chunks, n_pixels, pix_a, keys_a);
-    // 2. group them by root; the stable sort keeps raster order inside a
-    //    region and leaves the regions in root (= label) order
-    MF_HIP_CHECK(rocprim::radix_sort_pairs<PixelSortConfig>(
-        temp, tb, keys_a, keys_b, pix_a, pix_b, (size_t)n_pixels, 0u, (unsigned)pl.root_bits, s));
-    // 3. region starts
-    hipLaunchKernelGGL(chunk_count<true>, dim3(pl.pix_chunks), dim3(NT), 0, s,
-                       (const int16_t *)nullptr, keys_b, n_pixels, chunks);
-    hipLaunchKernelGGL(chunk_scan, dim3(1), dim3(SCAN_NT), 0, s, chunks, pl.pix_chunks,
-                       (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(emit_boundaries, dim3(pl.pix_chunks), dim3(NT), 0, s, keys_b, n_pixels,
-                       chunks, n_regions, offsets);
-    // 4. emission order of the regions: (plane, barcode), label order inside
-    {
-        const unsigned gq = (unsigned)((n_regions + NT - 1) / NT);
-        hipLaunchKernelGGL(region_keys, dim3(gq), dim3(NT), 0, s, keys_b, offsets, decoded,
-                           n_regions, n_pixels, H * W, conn3d, rkeys_a, ridx_a);
-    }
-    tb = pl.temp_bytes;
-    MF_HIP_CHECK(rocprim::radix_sort_pairs<RegionSortConfig>(
-        temp, tb, rkeys_a, rkeys_b, ridx_a, ridx_b, (size_t)n_regions, 0u,
-        (unsigned)pl.region_key_bits, s));
+    hipLaunchKernelGGL(run_expand, dim3(pl.run_chunks), dim3(NT), 0, s, skeys, svals, n_runs, n_pixels,
+                       chunks, n_pixels, pix, reg_start);
     // 5. per-region rows
     StatsArgs a;
-    a.pix = pix_b; a.span = ridx_b; a.n_pix = n_pixels; a.n_reg = n_regions;
+    a.pix = pix; a.start = reg_start; a.n_pix = n_pixels; a.n_reg = n_regions;
     a.dec = decoded; a.mag = magnitudes; a.dist = distances;
     a.dist_f64 = dist_dtype == MF_DTYPE_F64;
     a.traces = traces; a.tr_z = tr_z_stride; a.tr_b = tr_bit_stride; a.tr_p = tr_pix_stride;

@@ -23,7 +23,7 @@ on.  One of the FOVs is pure background (nothing decodes: NaN refactors), and
 the last bit is never seen, so its refactor is zero in every fragment (the
 ``refactors == 0 -> 1`` rule of optimize.py:333).
 
-Output: ``tests/golden/g7_optimize_trace.npz`` (data only).
+Output: ``tests/golden/optimize_trace_reference.npz`` (data only).
 """
 import os
 import sys
@@ -211,7 +211,7 @@ def main():
     for name, bgopt in (('plain_', False), ('bg_', True)):
         res = run_chain(optimize, codebook, images, Z, 6, bgopt, 4)
         out.update({name + k: v for k, v in res.items()})
-    path = os.path.join(OUT, 'g7_optimize_trace.npz')
+    path = os.path.join(OUT, 'optimize_trace_reference.npz')
     np.savez_compressed(path, **out)
     for name in ('plain_', 'bg_'):
         print(name, 'draw', out[name + 'it0_fov_index'].tolist(),

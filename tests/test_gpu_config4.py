@@ -129,14 +129,14 @@ def test_bench_two_ranks_gloo_one_card(gpu_device):
 def test_optimize_chain_matches_reference_trace(gpu_device, mode):
     """Two chained OptimizeIteration passes on the GPU against the trace the
     reference's own analysis/optimize.py produced on the same images
-    (tests/golden/g7_optimize_trace.npz): same fragment draws, per-fragment
+    (tests/golden/optimize_trace_reference.npz): same fragment draws, per-fragment
     refactors / counts, scale factors, backgrounds and histories.  Counts and
     the NaN / zero pattern are exact; values agree to the float32 rounding of
     the pixel magnitudes (the reference's go through BLAS sdot)."""
     import torch
     from conftest import GOLDEN_DIR
     from merlin_amd import optimize
-    g = np.load(os.path.join(GOLDEN_DIR, 'g7_optimize_trace.npz'))
+    g = np.load(os.path.join(GOLDEN_DIR, 'optimize_trace_reference.npz'))
     g7 = {k: g[k] for k in g.files}
     imgs = [torch.from_numpy(i).to(gpu_device) for i in g7['images']]
     hist = sum(optimize.pixel_histogram(d) for d in imgs)

@@ -1,6 +1,6 @@
 """CPU: OptimizeIteration's cross-fragment reduction against a trace made by
 the reference's own analysis/optimize.py (oracle/make_optimize_goldens.py ->
-tests/golden/g7_optimize_trace.npz): two chained iterations, fragment draws by
+tests/golden/optimize_trace_reference.npz): two chained iterations, fragment draws by
 the reference's constructor, per-fragment refactors incl. NaN rows (an empty
 field of view) and zeros (a bit that is never seen), optimize_background off
 and on.  Bar: bit-exact -- the reduction is the same numpy call sequence
@@ -17,7 +17,7 @@ from merlin_amd import optimize
 
 @pytest.fixture(scope='module')
 def g7():
-    g = np.load(os.path.join(GOLDEN_DIR, 'g7_optimize_trace.npz'))
+    g = np.load(os.path.join(GOLDEN_DIR, 'optimize_trace_reference.npz'))
     return {k: g[k] for k in g.files}
 
 
