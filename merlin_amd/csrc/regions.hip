@@ -371,10 +371,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v)
 // contiguous slice of `per` counts (a multiple of 4, read as independent
 // 16-byte loads: the kernel is pure latency)
 constexpr int SCAN_NT = 1024;
+// (block b scans the b-th of gridDim.x arrays laid out one after the other, each
+// padded to a multiple of 4 entries: `stride`; total[b] receives its sum)
 __global__ void __launch_bounds__(SCAN_NT)
-chunk_scan(int32_t *counts, int n_chunks, unsigned long long *total)
+chunk_scan(int32_t *counts, int n_chunks, unsigned long long *total, int stride = 0)
 {
     __shared__ int s_wave[SCAN_NT / 64];
+    counts += (size_t)blockIdx.x * stride;
+    if (total) total += blockIdx.x;
     const int per = ((n_chunks + SCAN_NT - 1) / SCAN_NT + 3) & ~3;
     const int lo = min(n_chunks, (int)threadIdx.x * per), hi = min(n_chunks, lo + per);
     const int hi4 = lo + ((hi - lo) & ~3);
@@ -697,10 +701,12 @@ region_stats(const StatsArgs a)
 // into the pixel list region_stats walks.
 
 // flags of the four pixels a thread owns: bit k = run start, bit 4 + k = run
-// end, bit 8 + k = region root (run start whose label is its own index)
+// end, bit 8 + k = region root (run start whose label is its own index);
+// lab[k] = the label of a run start.  32-bit arithmetic: the volume has fewer
+// than 2^31 pixels.
 __device__ __forceinline__ unsigned run_flags(const int16_t *__restrict__ dec,
-                                              const int32_t *__restrict__ L, int64_t i0,
-                                              int64_t n, int W)
+                                              const int32_t *__restrict__ L, uint32_t i0,
+                                              uint32_t n, uint32_t W, int32_t (&lab)[4])
 {
     if (i0 >= n) return 0u;
     int c[6];                       // c[0] = left neighbour, c[5] = right neighbour
@@ -708,23 +714,23 @@ __device__ __forceinline__ unsigned run_flags(const int16_t *__restrict__ dec,
         const ushort4 v = *reinterpret_cast<const ushort4 *>(dec + i0);
         c[1] = (int16_t)v.x; c[2] = (int16_t)v.y; c[3] = (int16_t)v.z; c[4] = (int16_t)v.w;
     } else {
-        for (int k = 0; k < 4; ++k) c[1 + k] = i0 + k < n ? (int)dec[i0 + k] : -1;
+        for (uint32_t k = 0; k < 4; ++k) c[1 + k] = i0 + k < n ? (int)dec[i0 + k] : -1;
     }
     if ((c[1] & c[2] & c[3] & c[4]) < 0) return 0u;          // four unassigned pixels
-    c[0] = i0 > 0 ? (int)dec[i0 - 1] : -1;
-    c[5] = i0 + 4 < n ? (int)dec[i0 + 4] : -1;
-    int x = (int)(i0 % W);
+    // the neighbours matter only beside an assigned pixel
+    c[0] = c[1] >= 0 && i0 > 0 ? (int)dec[i0 - 1] : -1;
+    c[5] = c[4] >= 0 && i0 + 4 < n ? (int)dec[i0 + 4] : -1;
+    uint32_t x = i0 % W;
     unsigned f = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (c[1 + k] >= 0) {
-            const bool start = x == 0 || c[k] != c[1 + k];
-            const bool end = x == W - 1 || c[2 + k] != c[1 + k];
-            if (start) {
+            if (x == 0 || c[k] != c[1 + k]) {
                 f |= 1u << k;
-                if (L[i0 + k] == (int32_t)(i0 + k)) f |= 0x100u << k;
+                lab[k] = L[i0 + k];
+                if (lab[k] == (int32_t)(i0 + k)) f |= 0x100u << k;
             }
-            if (end) f |= 0x10u << k;
+            if (x == W - 1 || c[2 + k] != c[1 + k]) f |= 0x10u << k;
         }
         if (++x == W) x = 0;
     }
@@ -743,8 +749,9 @@ run_count(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_
           int n_chunks, int32_t *__restrict__ counts)
 {
     __shared__ unsigned long long s_part[NT / 64];
-    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
-    unsigned long long v = pack3(run_flags(dec, L, i0, n, W));
+    const uint32_t i0 = blockIdx.x * (uint32_t)CHUNK + 4u * threadIdx.x;
+    int32_t lab[4];
+    unsigned long long v = pack3(run_flags(dec, L, i0, (uint32_t)n, (uint32_t)W, lab));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
@@ -753,42 +760,11 @@ run_count(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_
         unsigned long long t = 0;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) t += s_part[w];
+        const int cs = (n_chunks + 3) & ~3;       // arrays padded for chunk_scan's 16-byte loads
         counts[blockIdx.x] = (int32_t)(t & 0x1fffffu);
-        counts[n_chunks + blockIdx.x] = (int32_t)(t >> 21 & 0x1fffffu);
-        counts[2 * n_chunks + blockIdx.x] = (int32_t)(t >> 42);
+        counts[cs + blockIdx.x] = (int32_t)(t >> 21 & 0x1fffffu);
+        counts[2 * cs + blockIdx.x] = (int32_t)(t >> 42);
     }
-}
-
-// chunk_scan over `arrays` count arrays of n_chunks entries laid out one after
-// the other, one block each; totals[k] receives array k's sum
-__global__ void __launch_bounds__(SCAN_NT)
-chunk_scan_multi(int32_t *counts, int n_chunks, unsigned long long *totals)
-{
-    int32_t *c = counts + (size_t)blockIdx.x * n_chunks;
-    __shared__ int s_wave[SCAN_NT / 64];
-    const int per = ((n_chunks + SCAN_NT - 1) / SCAN_NT + 3) & ~3;
-    const int lo = min(n_chunks, (int)threadIdx.x * per), hi = min(n_chunks, lo + per);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += c[i];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) s_wave[w] = inc;
-    __syncthreads();
-    int base = 0;
-    for (int j = 0; j < w; ++j) base += s_wave[j];
-    int run = base + inc - sum;
-    for (int i = lo; i < hi; ++i) {
-        const int v = c[i];
-        c[i] = run;
-        run += v;
-    }
-    if (totals && hi == n_chunks && lo < n_chunks) totals[blockIdx.x] = (unsigned long long)run;
-    if (totals && n_chunks == 0 && threadIdx.x == 0) totals[blockIdx.x] = 0ull;
 }
 
 // Runs in raster order: first pixel, last pixel and region root of run i; the
@@ -802,8 +778,9 @@ run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t
          uint32_t *__restrict__ reg_key)
 {
     __shared__ unsigned long long s_wave[NT / 64];
-    const int64_t i0 = (int64_t)blockIdx.x * CHUNK + 4 * threadIdx.x;
-    const unsigned f = run_flags(dec, L, i0, n, W);
+    const uint32_t i0 = blockIdx.x * (uint32_t)CHUNK + 4u * threadIdx.x;
+    int32_t lab[4] = {0, 0, 0, 0};
+    const unsigned f = run_flags(dec, L, i0, (uint32_t)n, (uint32_t)W, lab);
     const unsigned long long mine = pack3(f);
     // exclusive prefix of the packed counts over the block's threads
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -819,10 +796,11 @@ run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t
 #pragma unroll
     for (int j = 0; j < NT / 64; ++j) base += j < w ? s_wave[j] : 0ull;
     const unsigned long long ex = base + inc - mine;
-    int64_t ps = (int64_t)offsets[blockIdx.x] + (int64_t)(ex & 0x1fffffu);
-    int64_t pe = (int64_t)offsets[n_chunks + blockIdx.x] + (int64_t)(ex >> 21 & 0x1fffffu);
-    int64_t pr = (int64_t)offsets[2 * n_chunks + blockIdx.x] + (int64_t)(ex >> 42);
     if (!f) return;
+    const int cs = (n_chunks + 3) & ~3;           // the count arrays' stride
+    uint32_t ps = (uint32_t)offsets[blockIdx.x] + (uint32_t)(ex & 0x1fffffu);
+    uint32_t pe = (uint32_t)offsets[cs + blockIdx.x] + (uint32_t)(ex >> 21 & 0x1fffffu);
+    uint32_t pr = (uint32_t)offsets[2 * cs + blockIdx.x] + (uint32_t)(ex >> 42);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int32_t p = (int32_t)(i0 + k);
@@ -830,7 +808,7 @@ run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t
             const bool root = f >> (8 + k) & 1u;
             if (ps < cap_runs) {
                 run_start[ps] = p;
-                run_root[ps] = root ? p : L[p];
+                run_root[ps] = lab[k];
             }
             ++ps;
             if (root) {
@@ -926,10 +904,10 @@ rs_scan(int32_t *__restrict__ cnt, const unsigned long long *n_dev, int64_t n_ho
     }
 }
 
-template <typename V>
+template <typename V, int NBITS>
 __global__ void __launch_bounds__(NT)
 rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
-           const unsigned long long *n_dev, int64_t n_host, int shift, int bins,
+           const unsigned long long *n_dev, int64_t n_host, int shift,
            const int32_t *__restrict__ cnt, const int32_t *__restrict__ totals,
            uint32_t *__restrict__ keys_out, V *__restrict__ vals_out)
 {
@@ -939,24 +917,33 @@ rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
     const int64_t t0 = (int64_t)blockIdx.x * RS_TILE;
     if (t0 >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int bins = 1 << NBITS;
     const uint32_t mask = (uint32_t)(bins - 1);
-    int nbits = 0;
-    while ((1 << nbits) < bins) ++nbits;
-    for (int b = threadIdx.x; b < (NT / 64) * RS_MAX_BINS; b += NT) (&cw[0][0])[b] = 0;
+#pragma unroll
+    for (int ww = 0; ww < NT / 64; ++ww)
+        for (int b = threadIdx.x; b < bins; b += NT) cw[ww][b] = 0;
     __syncthreads();
 
     uint32_t key[RS_IPT];
+    V val[RS_IPT];
     int rank[RS_IPT];
     const int64_t w0 = t0 + (int64_t)w * (RS_TILE / (NT / 64));
+    // every load of the tile is issued before the first one is used
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const int64_t i = w0 + k * 64 + lane;
+        key[k] = i < n ? keys_in[i] : 0u;
+        val[k] = i < n ? vals_in[i] : V(0);
+    }
 #pragma unroll
     for (int k = 0; k < RS_IPT; ++k) {
         const int64_t i = w0 + k * 64 + lane;
         const bool valid = i < n;
-        key[k] = valid ? keys_in[i] : 0u;
         const uint32_t d = (key[k] >> shift) & mask;
         // lanes of this step with the same digit
         unsigned long long peers = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
+#pragma unroll
+        for (int b = 0; b < NBITS; ++b) {
             const unsigned long long vote = __ballot((d >> b) & 1u);
             peers &= (d >> b) & 1u ? vote : ~vote;
         }
@@ -1021,7 +1008,7 @@ rs_scatter(const uint32_t *__restrict__ keys_in, const V *__restrict__ vals_in,
             const uint32_t d = (key[k] >> shift) & mask;
             const int64_t dst = (int64_t)cw[w][d] + rank[k];
             keys_out[dst] = key[k];
-            vals_out[dst] = vals_in[i];
+            vals_out[dst] = val[k];
         }
     }
 }
@@ -1065,8 +1052,16 @@ int radix_sort(uint32_t *keys_a, uint32_t *keys_b, V *vals_a, V *vals_b,
         hipLaunchKernelGGL(rs_hist, dim3(tiles), dim3(NT), 0, s, ki, n_dev, n_host, shift, bins, cnt);
         hipLaunchKernelGGL(rs_scan, dim3((unsigned)((bins + 63) / 64)), dim3(64 * RS_SEGS), 0, s, cnt,
                            n_dev, n_host, bins, totals);
-        hipLaunchKernelGGL(rs_scatter<V>, dim3(tiles), dim3(NT), 0, s, ki, vi, n_dev, n_host, shift,
-                           bins, cnt, totals, ko, vo);
+        switch (p.digit_bits[k]) {
+#define MF_RS_CASE(NB)                                                                             \
+    case NB:                                                                                       \
+        hipLaunchKernelGGL((rs_scatter<V, NB>), dim3(tiles), dim3(NT), 0, s, ki, vi, n_dev, n_host, \
+                           shift, cnt, totals, ko, vo);                                            \
+        break;
+            MF_RS_CASE(1) MF_RS_CASE(2) MF_RS_CASE(3) MF_RS_CASE(4) MF_RS_CASE(5)
+            MF_RS_CASE(6) MF_RS_CASE(7) MF_RS_CASE(8) MF_RS_CASE(9) MF_RS_CASE(10)
+#undef MF_RS_CASE
+        }
         shift += p.digit_bits[k];
         where ^= 1;
     }
@@ -1186,8 +1181,8 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     pl.reg_key_b = off; off += align_up(nr * 4);
     pl.reg_start = off; off += align_up((nr + 1) * 4);
     pl.aux = off; off += align_up((size_t)vol * 4);
-    const size_t n_chunk_ints = (size_t)3 * pl.vol_chunks > (size_t)pl.run_chunks
-                                    ? (size_t)3 * pl.vol_chunks : (size_t)pl.run_chunks;
+    const size_t n_chunk_ints = (size_t)3 * (pl.vol_chunks + 4) > (size_t)pl.run_chunks
+                                    ? (size_t)3 * (pl.vol_chunks + 4) : (size_t)pl.run_chunks;
     pl.chunks = off; off += align_up(n_chunk_ints * 4);
     pl.totals = off; off += align_up(4 * 8);
     pl.sort_cnt = off; off += align_up(tiles * RS_MAX_BINS * 4);
@@ -1627,7 +1622,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     //    and the regions' roots in label order with their (plane, barcode) key
     hipLaunchKernelGGL(run_count, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol, W,
                        pl.vol_chunks, chunks);
-    hipLaunchKernelGGL(chunk_scan_multi, dim3(3), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks, totals);
+    hipLaunchKernelGGL(chunk_scan, dim3(3), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks, totals,
+                       (pl.vol_chunks + 3) & ~3);
     hipLaunchKernelGGL(run_emit, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol, W,
                        pl.vol_chunks, chunks, n_pixels, n_regions, H * W, conn3d, run_start, run_end,
                        run_root, reg_root_a, reg_key_a);
