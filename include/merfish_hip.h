@@ -228,6 +228,27 @@ int mf_region_frame_typed(const double *rec, const float *inten,
                           float *out_inten, double *out_xy64, int64_t *count,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The per-barcode reductions of extract_refactors and _extract_backgrounds
+ * (merlin/util/decoding.py:321-334, 355-370) from the region table, in float64
+ * like the reference.  For every barcode b, over the rows of z plane `plane`
+ * (-1: every plane, in plane order) with area >= area_threshold, in the
+ * table's row order (= the reference's label order):
+ *   seen[b]    = number of those rows                       (barcodesSeen)
+ *   normalize: sums[b,:] = sum of  w / ||w|| / seen[b],  w = stat[r,:] - h_offset
+ *              (stat = mean_tm; h_offset = the background refactors, decoding.py:
+ *              328-332)
+ *   else:      sums[b,:] = sum of  stat[r,:] - h_offset
+ *              (stat = min_tm, area_threshold 5: decoding.py:362-369)
+ *   rec, stat  the table of mf_region_table (2-D mode); h_offset HOST f64[B] or
+ *              NULL; sums f64 [N,B]; seen f64 [N]
+ * The caller finishes on the host ([N,B] arithmetic: NaN at off-bits, nanmean,
+ * ratio).  Eight rows are accumulated side by side and added at the end, so
+ * the sums agree with the reference's sequential ones to float64 rounding. */
+int mf_refactor_sums(const double *rec, const float *stat, int64_t n_regions,
+                     int B, int N, int Z, int plane, double area_threshold,
+                     const double *h_offset, int normalize, double *sums,
+                     double *seen, void *stream);
+
 /* mf_region_frame without a workspace argument, for callers that cannot
  * allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, results

@@ -31,7 +31,7 @@ MF_FRAME_STATIC_MAX_ROWS = 1048576
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
            'mf_codebook_table_bytes', 'mf_codebook_prepare',
            'mf_decode_pixels', 'mf_label_components',
-           'mf_region_workspace_bytes', 'mf_region_table',
+           'mf_region_workspace_bytes', 'mf_region_table', 'mf_refactor_sums',
            'mf_region_frame_workspace_bytes', 'mf_region_frame',
            'mf_region_frame_static', 'mf_region_frame_typed',
            'mf_high_pass_filter', 'mf_preprocess_workspace_bytes',
@@ -82,6 +82,9 @@ def lib():
     L.mf_region_table.argtypes = [
         vp, vp, vp, i32, vp, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64,
         i64, vp, vp, vp, vp, vp, i64, vp]
+    L.mf_refactor_sums.restype = i32
+    L.mf_refactor_sums.argtypes = [vp, vp, i64, i32, i32, i32, i32, f64, vp, i32,
+                                   vp, vp, vp]
     L.mf_region_frame_workspace_bytes.restype = i64
     L.mf_region_frame_workspace_bytes.argtypes = [i64]
     L.mf_region_frame.restype = i32

@@ -1191,6 +1191,130 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
     return MF_OK;
 }
 
+// ------------------------------------------------- refactor sums (K5) ---
+// extract_refactors / _extract_backgrounds (decoding.py:321-334, 355-370) reduce
+// the regions of every barcode to one row of per-bit sums.  One workgroup per
+// barcode walks that barcode's rows of the region table (grouped by plane, then
+// barcode, in label order: the reference's loop order), eight rows at a time,
+// 32 lanes = the bits of one row; float64 throughout like the reference.
+struct RefactorArgs {
+    const double *rec;
+    const float *stat;        // mean_tm (refactors) or min_tm (backgrounds)
+    int64_t n_reg;
+    int B, N, plane, Z, normalize;
+    double area_thr;
+    double offset[MF_MAX_BITS];
+    double *sums, *seen;
+};
+
+// first row whose (plane, barcode) key is >= (p, b)
+__device__ __forceinline__ int64_t refactor_lower_bound(const double *rec, int64_t n, double p,
+                                                        double b)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const double rp = rec[mid * MF_REC_COLS + 1], rb = rec[mid * MF_REC_COLS + 0];
+        if (rp < p || (rp == p && rb < b)) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(NT)
+refactor_sums(const RefactorArgs a)
+{
+    constexpr int GROUPS = NT / 32;
+    __shared__ double s_part[GROUPS][32];
+    __shared__ int s_cnt[GROUPS];
+    __shared__ int64_t s_range[2];
+    const int code = blockIdx.x;
+    const int bit = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const bool has = bit < a.B;
+    const double off = has ? a.offset[bit] : 0.0;
+    const int p_lo = a.plane < 0 ? 0 : a.plane, p_hi = a.plane < 0 ? a.Z : a.plane + 1;
+
+    // pass 1: how many of the barcode's regions are large enough
+    int mine = 0;
+    for (int p = p_lo; p < p_hi; ++p) {
+        if (threadIdx.x == 0) {
+            s_range[0] = refactor_lower_bound(a.rec, a.n_reg, (double)p, (double)code);
+            s_range[1] = refactor_lower_bound(a.rec, a.n_reg, (double)p, (double)code + 1.0);
+        }
+        __syncthreads();
+        const int64_t lo = s_range[0], hi = s_range[1];
+        for (int64_t r = lo + threadIdx.x; r < hi; r += NT)
+            mine += a.rec[r * MF_REC_COLS + 2] >= a.area_thr;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 32);
+    if (bit == 0) s_cnt[grp] = mine;
+    __syncthreads();
+    int seen = 0;
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) seen += s_cnt[g];
+    __syncthreads();
+
+    // pass 2: the rows in order, group g taking every GROUPS-th one
+    double acc = 0.0;
+    for (int p = p_lo; p < p_hi; ++p) {
+        if (threadIdx.x == 0) {
+            s_range[0] = refactor_lower_bound(a.rec, a.n_reg, (double)p, (double)code);
+            s_range[1] = refactor_lower_bound(a.rec, a.n_reg, (double)p, (double)code + 1.0);
+        }
+        __syncthreads();
+        const int64_t lo = s_range[0], hi = s_range[1];
+        for (int64_t r = lo + grp; r < hi; r += GROUPS) {
+            if (!(a.rec[r * MF_REC_COLS + 2] >= a.area_thr)) continue;     // uniform per group
+            double v = has ? (double)a.stat[r * a.B + bit] - off : 0.0;
+            if (a.normalize) {
+                // np.linalg.norm of the row, then the row's share of the mean
+                double sq = v * v;
+#pragma unroll
+                for (int d = 16; d > 0; d >>= 1) sq += __shfl_xor(sq, d, 32);
+                v = v / sqrt(sq) / (double)seen;
+            }
+            acc += v;
+        }
+        __syncthreads();
+    }
+    s_part[grp][bit] = acc;
+    __syncthreads();
+    if (grp == 0 && has) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) t += s_part[g][bit];
+        a.sums[(int64_t)code * a.B + bit] = t;
+    }
+    if (threadIdx.x == 0) a.seen[code] = (double)seen;
+}
+
+}  // namespace
+
+extern "C" int mf_refactor_sums(const double *rec, const float *stat, int64_t n_regions, int B, int N,
+                                int Z, int plane, double area_threshold, const double *h_offset,
+                                int normalize, double *sums, double *seen, void *stream)
+{
+    if (!sums || !seen || (n_regions > 0 && (!rec || !stat)))
+        return mf::fail(MF_EINVAL, "null pointer argument");
+    if (B < 1 || B > MF_MAX_BITS || N < 1 || N > 32767 || Z < 1 || plane >= Z || n_regions < 0)
+        return mf::fail(MF_EINVAL, "bad sizes B=%d N=%d Z=%d plane=%d", B, N, Z, plane);
+    RefactorArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rec = rec; a.stat = stat; a.n_reg = n_regions;
+    a.B = B; a.N = N; a.plane = plane; a.Z = Z; a.normalize = normalize != 0;
+    a.area_thr = area_threshold;
+    for (int b = 0; b < B; ++b) a.offset[b] = h_offset ? h_offset[b] : 0.0;
+    a.sums = sums; a.seen = seen;
+    hipLaunchKernelGGL(refactor_sums, dim3((unsigned)N), dim3(NT), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    MF_HIP_CHECK(hipGetLastError());
+    return MF_OK;
+}
+
+namespace {
+
 // ------------------------------------------------------------ frame rows ---
 
 struct KeepRow {

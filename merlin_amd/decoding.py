@@ -41,33 +41,6 @@ def normalize(x):
         return x
 
 
-def _row_norms(m: np.ndarray) -> np.ndarray:
-    """np.linalg.norm of every row of a float64 [n, B] matrix with the bits of
-    the per-row call the reference makes (decoding.py:329-331): norm() of a
-    float64 vector is sqrt(x.dot(x)), and a stacked [n,1,B] @ [n,B,1] matmul
-    runs that same BLAS dot once per row (tests/test_optimize_dist.py checks the
-    identity on this numpy)."""
-    m = np.ascontiguousarray(m, dtype=np.float64)
-    if m.shape[0] == 0:
-        return np.zeros(0)
-    return np.sqrt(np.matmul(m[:, None, :], m[:, :, None])[:, 0, 0])
-
-
-def _sum_rows_by_code(ids: np.ndarray, rows: np.ndarray, count: int
-                      ) -> np.ndarray:
-    """out[ids[k]] += rows[k] for k in order (the reference's running sums per
-    barcode in region order, decoding.py:329-332, 366-370): one weighted
-    bincount over (code, bit) cells, which accumulates sequentially in input
-    order."""
-    bits = rows.shape[1]
-    if not len(ids):
-        return np.zeros((count, bits))
-    cell = (np.asarray(ids, dtype=np.intp)[:, None] * bits
-            + np.arange(bits, dtype=np.intp)[None, :]).ravel()
-    return np.bincount(cell, weights=np.ascontiguousarray(rows).ravel(),
-                       minlength=count * bits).reshape(count, bits)
-
-
 # Frame rows are staged in HBM and moved to the host by the copy engine.
 # False has the gather kernel write them over PCIe into mapped pinned memory
 # instead, which costs the next FOV's decode kernel 5 % (measured; more with more
@@ -827,39 +800,66 @@ class PixelBasedDecoder(object):
 
     # ---------------------------------------------------- extract_refactors --
 
-    def _refactors_from_table(self, table: RegionTable, rows,
-                              extractBackgrounds: bool):
+    def _refactor_sums(self, table: RegionTable, stat, Z, plane,
+                       areaThreshold, offset, normalize):
+        """mf_refactor_sums: (sums float64 [N,B], seen float64 [N]) on the
+        host; one small device-to-host copy."""
+        import ctypes
+        L = _lib.lib()
         N, B = self._barcodeCount, self._bitCount
-        if rows is None:                 # every row: no gather copies
-            rows = slice(None)
-        ids = table.rec[rows, 0].astype(np.int64)
-        area = table.rec[rows, 2]
+        dev = table.rec_d.device
+        with torch.cuda.device(dev):
+            out = torch.empty(N * B + N, dtype=torch.float64, device=dev)
+            off = None
+            if offset is not None:
+                off = np.ascontiguousarray(offset, dtype=np.float64)
+            _lib.check(L.mf_refactor_sums(
+                table.rec_d.data_ptr(), stat.data_ptr(), len(table), B, N,
+                int(Z), -1 if plane is None else int(plane),
+                float(areaThreshold),
+                None if off is None
+                else off.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                int(normalize), out.data_ptr(), out[N * B:].data_ptr(),
+                _stream_ptr(dev)))
+            host = out.cpu().numpy()
+        return host[:N * B].reshape(N, B), host[N * B:]
+
+    def _refactors_from_table(self, table: RegionTable, Z, plane,
+                              extractBackgrounds: bool):
+        """extract_refactors' reductions (decoding.py:290-377) from the region
+        table: the per-barcode sums over regions on the GPU
+        (mf_refactor_sums), the [N,B] arithmetic that follows here."""
+        N, B = self._barcodeCount, self._bitCount
+        import warnings
+        if len(table) == 0:
+            seen = np.zeros(N)
+            sumPixelTraces = np.zeros((N, B))
+            sumMin = np.zeros((N, B))
+            seenBg = np.zeros(N)
         if extractBackgrounds:
             # decoding.py:342-377, area threshold 5 hard-coded at :362
-            sel = area >= 5
-            seenBg = np.bincount(ids[sel], minlength=N).astype(np.float64)
-            sumMin = _sum_rows_by_code(
-                ids[sel], table.min_tm[rows][sel].astype(np.float64), N)
+            if len(table):
+                sumMin, seenBg = self._refactor_sums(
+                    table, table.min_tm_d, Z, plane, 5, None, False)
             off = sumMin.copy()
             off[self._decodingMatrix > 0] = np.nan
-            with np.errstate(invalid='ignore', divide='ignore'):
+            with np.errstate(invalid='ignore', divide='ignore'), \
+                    warnings.catch_warnings():
+                warnings.simplefilter('ignore', category=RuntimeWarning)
                 backgroundRefactors = np.nansum(off, axis=0) / np.sum(
                     (self._decodingMatrix == 0) * seenBg[:, np.newaxis],
                     axis=0)
         else:
             backgroundRefactors = np.zeros(B)
-
-        sel = area >= self.refactorAreaThreshold
-        barcodesSeen = np.bincount(ids[sel], minlength=N).astype(np.float64)
-        mean = table.mean_tm[rows][sel].astype(np.float64) \
-            - backgroundRefactors
-        with np.errstate(invalid='ignore', divide='ignore'):
-            norm = _row_norms(mean)
-            contrib = (mean / norm[:, None]) / barcodesSeen[ids[sel]][:, None]
-        sumPixelTraces = _sum_rows_by_code(ids[sel], contrib, N)
+        if len(table):
+            sumPixelTraces, seen = self._refactor_sums(
+                table, table.mean_tm_d, Z, plane, self.refactorAreaThreshold,
+                backgroundRefactors, True)
+            sumPixelTraces = sumPixelTraces.copy()
+        barcodesSeen = np.array(seen, dtype=np.float64)
         sumPixelTraces[self._decodingMatrix == 0] = np.nan
-        import warnings
-        with warnings.catch_warnings():
+        with warnings.catch_warnings(), np.errstate(invalid='ignore',
+                                                    divide='ignore'):
             warnings.simplefilter('ignore', category=RuntimeWarning)
             onBitIntensity = np.nanmean(sumPixelTraces, axis=0)
             refactors = onBitIntensity / np.mean(onBitIntensity)
@@ -874,11 +874,13 @@ class PixelBasedDecoder(object):
         vol = self._lookup(decodedImage, pixelMagnitudes,
                            normalizedPixelTraces, None)
         table = self.region_table(vol, False, True)
-        return self._refactors_from_table(table, None, extractBackgrounds)
+        return self._refactors_from_table(table, vol.shape[0], None,
+                                          extractBackgrounds)
 
     def extract_refactors_device(self, vol: DecodedVolume,
                                  extractBackgrounds=False, zPlane=None):
+        """extract_refactors on a device-resident volume; zPlane selects one
+        plane of a multi-plane volume (None: every region of the volume)."""
         table = self.region_table(vol, False, True)
-        rows = None if zPlane is None \
-            else np.nonzero(table.rec[:, 1] == zPlane)[0]
-        return self._refactors_from_table(table, rows, extractBackgrounds)
+        return self._refactors_from_table(table, vol.shape[0], zPlane,
+                                          extractBackgrounds)

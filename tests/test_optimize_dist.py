@@ -241,32 +241,3 @@ def test_shard_fovs():
     assert shard_fovs([], 0, 3) == []
     with pytest.raises(ValueError):
         shard_fovs([1], 2, 2)
-
-
-def test_row_norms_have_the_bits_of_per_row_linalg_norm():
-    # extract_refactors normalises one vector per region (decoding.py:329-331);
-    # the host does all rows in one stacked matmul and must keep those bits
-    from merlin_amd.decoding import _row_norms
-    rng = np.random.default_rng(5)
-    for bits in (16, 22, 32, 5):
-        m = rng.normal(size=(20000, bits)) * rng.uniform(1e-3, 1e3, size=(20000, 1))
-        m[7] = 0.0
-        want = np.array([np.linalg.norm(v) for v in m])
-        assert np.array_equal(_row_norms(m), want)
-        assert np.array_equal(_row_norms(np.asfortranarray(m)), want)
-    assert _row_norms(np.zeros((0, 16))).shape == (0,)
-
-
-def test_sum_rows_by_code_keeps_sequential_order():
-    from merlin_amd.decoding import _sum_rows_by_code
-    rng = np.random.default_rng(6)
-    ids = rng.integers(0, 140, size=30000)
-    rows = rng.normal(size=(30000, 16)) * rng.uniform(1e-6, 1e6, size=(30000, 1))
-    want = np.zeros((140, 16))
-    np.add.at(want, ids, rows)
-    assert np.array_equal(_sum_rows_by_code(ids, rows, 140), want)
-    seq = np.zeros((140, 16))
-    for k in range(2000):
-        seq[ids[k]] += rows[k]
-    assert np.array_equal(_sum_rows_by_code(ids[:2000], rows[:2000], 140), seq)
-    assert not _sum_rows_by_code(ids[:0], rows[:0], 140).any()
