@@ -486,8 +486,12 @@ def main():
 
     # table / staging buffers are carved from torch's caching allocator: give it
     # its working set up front (three FOVs in flight) so that no timed FOV pays a
-    # hipMalloc because it is a little larger than every block cached so far
-    task.reserve_memory(fovs[0].shape)
+    # hipMalloc because it is a little larger than every block cached so far;
+    # and the page-locked blocks of the frame rows, read once (the first CPU
+    # access to a page of a fresh hipHostMalloc block faults: without this the
+    # first ~20 FOVs of a process hand their rows over 1.3 ms slower each,
+    # dev/first_fovs.py)
+    task.reserve_memory(fovs[0].shape, expectedBarcodes=Z * SPOTS_PER_PLANE)
 
     # A step = one FOV through Decode.run_fovs (stack in HBM -> barcode DataFrame
     # on the host).  Steady state: `steps` FOVs through a full pipeline; cold:
@@ -516,6 +520,11 @@ def main():
     # the two events of a pair ----
     px_fov = Z * H * W
     k_ms = sum(a.elapsed_time(b) for a, b in k_events) / max(len(k_events), 1)
+    # the pipeline's period: decode-kernel start to decode-kernel start inside
+    # the window.  The window itself is steps x period + the drain of the last
+    # FOV's labelling / table / rows (about 1 ms: 3 % at 20 steps, 0.3 % at 200)
+    period_ms = (k_events[0][0].elapsed_time(k_events[-1][0]) / (len(k_events) - 1)
+                 if len(k_events) > 1 else None)
     # the same kernel with the GPU to itself (in the timed region it shares the
     # CUs with the previous FOV's sort / region statistics on a second stream)
     for r in range(12):
@@ -734,6 +743,7 @@ def main():
         }
         if dt_cold is not None:
             out['ms_per_step_cold'] = dt_cold / args.steps * 1e3
+        out['fov_period_ms'] = period_ms
         if host_line is not None:
             out['host_pipeline'] = host_line
         if image_line is not None:

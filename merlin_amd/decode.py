@@ -98,7 +98,8 @@ class Decode(object):
                 self._lbl = torch.cuda.Stream(dev)
         return self._lbl
 
-    def reserve_memory(self, stackShape, fovsInFlight=None):
+    def reserve_memory(self, stackShape, fovsInFlight=None,
+                       expectedBarcodes=None, typed=False):
         """Give torch's caching allocator the working set of the FOV loop up
         front: one block per stream of the pipeline (the allocator keeps a pool
         per stream), allocated and released at once, from which the per-FOV
@@ -106,7 +107,17 @@ class Decode(object):
         Without it the pool grows by a hipMalloc (5-8 ms) whenever a FOV needs a
         slightly larger table than any before it.  Optional; sizes are upper
         estimates for ``stackShape`` = (B, Z, H, W) and are capped at half the
-        free memory."""
+        free memory.
+
+        With ``expectedBarcodes`` (regions per FOV, an estimate) the page-locked
+        blocks that carry the frame rows to the host are set up as well: a
+        hipHostMalloc costs about 0.1 ms, but the first CPU access to each page
+        of such a block faults (about 1 us a page here), which makes the
+        DataFrame hand-over of the first twenty or so FOVs 1.3 ms slower each
+        until every block of torch's pinned pool has been read once
+        (dev/first_fovs.py).  The blocks are allocated in the shapes
+        ``_frame_enqueue`` asks for (``typed``: those of the database path),
+        read once and released to that pool."""
         B, Z, H, W = (int(v) for v in stackShape)
         px = Z * H * W
         n = fovsInFlight or (self.decodeAhead + self.frameLag + 2)
@@ -126,6 +137,28 @@ class Decode(object):
                 elif nbytes:
                     with torch.cuda.stream(stream):
                         torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if expectedBarcodes:
+            from merlin_amd import _lib
+            m = int(expectedBarcodes)
+            if typed:
+                shapes = [((2, m), torch.uint16),
+                          ((_lib.MF_TYPED_F32_COLS, m), torch.float32),
+                          ((m,), torch.int32), ((2, m), torch.float64)]
+            else:
+                shapes = [((_lib.MF_FRAME_COLS, m), torch.float64)]
+            shapes.append(((B, m), torch.float32))
+            # torch's pinned pool hands out blocks of 2^k bytes: ask for whole
+            # blocks, twice the FOVs in flight (a block returns to the pool
+            # only after the consumer has dropped the FOV's DataFrame)
+            blocks = []
+            for sh, dt in shapes:
+                nbytes = int(np.prod(sh)) * torch.empty((), dtype=dt).element_size()
+                nbytes = 1 << max(nbytes - 1, 1).bit_length()
+                blocks += [self.decoder._pinned((nbytes,), torch.uint8)
+                           for _ in range(2 * n)]
+            for t in blocks:
+                t[::4096].sum()     # one byte of every page
+            del blocks
 
     def flush_images(self):
         """Wait until every decoded-image file queued so far is on disk."""
