@@ -156,6 +156,16 @@ __device__ __forceinline__ float score_key(float s, int slot)
     return __int_as_float((__float_as_int(s) & ~KEY_SLOT_MASK) | slot);
 }
 
+// SEARCH_GROUPED (large codebooks): the keys carry no slot; the winner is found
+// afterwards among the 16 codewords of the recorded tile that the lane holds
+enum { SEARCH_TOP2 = 0, SEARCH_EXCLUSIVE = 1, SEARCH_GROUPED = 2 };
+template <bool TAG>
+__device__ __forceinline__ float tile_key(float s, int slot)
+{
+    if constexpr (TAG) return score_key(s, slot);
+    else return s;
+}
+
 // v_min3_f32 without the canonicalisation the compiler puts in front of fminf
 // (keys are never NaN)
 __device__ __forceinline__ float fmin3(float a, float b, float c)
@@ -310,6 +320,25 @@ constexpr bool tiles_in_sequence(int maxb) { return maxb <= 16 ? MF_SEQ16 : MF_S
 #define MF_FENCE() ((void)0)
 #endif
 
+// instruction order of a step of the software-pipelined codeword scan: one
+// matrix instruction, MF_PIPE_VALU vector instructions, four times over, then
+// whatever is left; a full fence ends the step
+#ifndef MF_PIPE_VALU
+#define MF_PIPE_VALU 0
+#endif
+#if MF_PIPE_VALU > 0
+#define MF_INTERLEAVE()                                                   \
+    do {                                                                  \
+        for (int q_ = 0; q_ < 4; ++q_) {                                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
+            __builtin_amdgcn_sched_group_barrier(0x002, MF_PIPE_VALU, 0); \
+        }                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define MF_INTERLEAVE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // timing-only ablations (wrong results): no workgroup barriers in the blur
 #ifdef MF_ABL_NOBARRIER
 #define MF_TILE_SYNC() ((void)0)
@@ -346,11 +375,13 @@ __device__ __forceinline__ double exact_d2(const float (&x)[MAXB], uint32_t mask
 
 // FULL: B == MAXB and the reciprocal division applies, both known at compile
 // time (the common 16-bit / 32-bit codebooks): no per-bit guards.
-template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, bool EXCL>
+template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, int SM>
 __global__ void __launch_bounds__(NTHREADS, waves_per_simd(MAXB, UNI))
 decode_kernel(const DecodeArgs a)
 {
     using HT = typename HType<PIX>::type;
+    constexpr bool EXCL = SM == SEARCH_EXCLUSIVE;
+    constexpr bool TAG = SM != SEARCH_GROUPED;
     constexpr bool IS_U16 = std::is_same<PIX, uint16_t>::value;
     constexpr int TH = NWAVES * PPT;
     constexpr int RH = TH + 2 * R;                 // rows staged per bit
@@ -846,114 +877,127 @@ decode_kernel(const DecodeArgs a)
 #endif
                 const int cn = min(a.chunk, a.Npad - c0);
                 if (!single_chunk) {
+#if defined(MF_ABL_NOCHUNKSYNC)      // timing only (wrong results)
+                    if (c0 == 0 && o == 0) load_chunk(c0, cn);
+#elif defined(MF_ABL_NOCHUNKLOAD)
+                    __syncthreads();
+                    if (c0 == 0 && o == 0) load_chunk(c0, cn);
+                    __syncthreads();
+#else
                     __syncthreads();            // previous chunk fully consumed
                     load_chunk(c0, cn);
                     __syncthreads();
+#endif
                 }
-                for (int ct = 0; ct < cn; ct += 32) {
-                    const int rows_left = a.N - (c0 + ct);     // real codewords from this tile on
-                    // A operand: 8 elements of codeword (ct + lane&31), bits 16ks + 8*half ..
-                    u32x4 af[KS];
+                // A operand: 8 elements of codeword (ct + lane&31), bits 16ks + 8*half ..
+                auto load_a = [&](int ct, u32x4 (&af)[KS]) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         af[ks] = *reinterpret_cast<const u32x4 *>(
                             lds_a + ((size_t)(ct + (lane & 31)) * MAXB +
                                      8 * ((2 * ks + half) ^ a_swz)) * 2);
-                    if constexpr (tiles_in_sequence(MAXB)) {
-                    // one pixel tile at a time: 16 accumulator registers instead
-                    // of 32; with three or four waves per SIMD the other waves
-                    // cover the MFMA latency
+                };
+                // the table entries are -t (t = 1, or 1/2 above 16 bits), so acc =
+                // -t * (sum of the on bits).  For a uniform codebook that is the
+                // key: d^2 / 2 = 1 + acc * v / t for a unit trace.  (The zero start
+                // is an MFMA inline constant.)
+                auto chain = [&](const u32x4 (&af)[KS], int tt, f32x16 &acc) {
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        f32x16 acc1;
+                    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc1[i] = 0.0f;
+                    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                        for (int ks = 0; ks < KS; ++ks)
+                        for (int s = 0; s < NSPLIT; ++s) {
+                            u32x4 bv;
+                            bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
+                            bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
+                            acc = mfma_tile(af[ks], bv, acc);
+                        }
+                };
+                // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of pixel
+                // (lane&31) + 32*tt in accumulator slot i.  Zero padding rows of a
+                // uniform table are caught after the merge.
+                auto fold = [&](Top2 &t, const f32x16 &acc, int ct, auto trim) {
+                    const int rows_left = a.N - (c0 + ct);     // real codewords from this tile on
+                    const float before = t.best;
 #pragma unroll
-                            for (int s = 0; s < NSPLIT; ++s) {
-                                u32x4 bv;
-                                bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
-                                bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
-                                acc1 = mfma_tile(af[ks], bv, acc1);
-                            }
-                        const float before = st[tt].best;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            // rows 16-31 of the codebook's last tile are padding
-                            // when at most 16 codewords are left: accumulator
-                            // slots 8-15 (gq 2, 3) cannot win
+                    for (int gq = 0; gq < 4; ++gq) {
+                        // rows 16-31 of the codebook's last tile are padding when at
+                        // most 16 codewords are left: accumulator slots 8-15 (gq 2,
+                        // 3) cannot win (skipped where the codebook has few tiles;
+                        // the pipelined scan stays free of branches)
+                        if constexpr (decltype(trim)::value)
                             if (gq == 2 && rows_left <= 16) break;
-                            float s4[4];
-                            if constexpr (UNI) {
+                        float s4[4];
+                        if constexpr (UNI) {
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) s4[i] = acc1[4 * gq + i];
-                            } else {
-                                const int nl = ct + 8 * gq + 4 * half;
-                                const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
-                                const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
-                                s4[0] = fmaf(vv.x, acc1[4 * gq + 0], hh.x);
-                                s4[1] = fmaf(vv.y, acc1[4 * gq + 1], hh.y);
-                                s4[2] = fmaf(vv.z, acc1[4 * gq + 2], hh.z);
-                                s4[3] = fmaf(vv.w, acc1[4 * gq + 3], hh.w);
-                            }
-                            top2_update4<EXCL>(st[tt], score_key(s4[0], 4 * gq + 0),
-                                         score_key(s4[1], 4 * gq + 1), score_key(s4[2], 4 * gq + 2),
-                                         score_key(s4[3], 4 * gq + 3));
+                            for (int i = 0; i < 4; ++i) s4[i] = acc[4 * gq + i];
+                        } else {
+                            // (1 + |c|^2) / 2 - v * sum = d^2 / 2
+                            const int nl = ct + 8 * gq + 4 * half;
+                            const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
+                            const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
+                            s4[0] = fmaf(vv.x, acc[4 * gq + 0], hh.x);
+                            s4[1] = fmaf(vv.y, acc[4 * gq + 1], hh.y);
+                            s4[2] = fmaf(vv.z, acc[4 * gq + 2], hh.z);
+                            s4[3] = fmaf(vv.w, acc[4 * gq + 3], hh.w);
                         }
-                        st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
+                        top2_update4<EXCL>(t, tile_key<TAG>(s4[0], 4 * gq + 0),
+                                           tile_key<TAG>(s4[1], 4 * gq + 1),
+                                           tile_key<TAG>(s4[2], 4 * gq + 2),
+                                           tile_key<TAG>(s4[3], 4 * gq + 3));
                     }
+                    t.tile = t.best != before ? c0 + ct : t.tile;
+                };
+                if constexpr (tiles_in_sequence(MAXB)) {
+                    // one pixel tile at a time: 16 accumulator registers instead of
+                    // 32; with three or four waves per SIMD the other waves cover
+                    // the MFMA latency
+                    for (int ct = 0; ct < cn; ct += 32) {
+                        u32x4 af[KS];
+                        load_a(ct, af);
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            f32x16 acc1;
+                            chain(af, tt, acc1);
+                            fold(st[tt], acc1, ct, std::true_type());
+                        }
+                    }
+                } else {
+                    // software pipeline over the (codeword tile, pixel tile) steps:
+                    // the four matrix instructions of the next step (a dependent
+                    // chain, 32 clocks each) are issued between the fold
+                    // instructions of the current one, so that the matrix core and
+                    // the vector ALU of a SIMD both work from ONE wave (left to
+                    // itself the compiler issues the chain first: the wave then
+                    // waits 96 clocks on it and the fold runs beside the last
+                    // instruction only); the A operand of the next codeword tile
+                    // is read from LDS a whole step ahead
+                    f32x16 acc0, acc1;
+                    u32x4 afa[KS], afb[KS];
+                    load_a(0, afa);
+                    chain(afa, 0, acc0);
+                    // af: this codeword tile's A operand, afn: the next one's
+                    auto step = [&](int ct, const u32x4 (&af)[KS], u32x4 (&afn)[KS], auto more) {
+                        if constexpr (decltype(more)::value) load_a(ct + 32, afn);
+                        chain(af, 1, acc1);
+                        fold(st[0], acc0, ct, std::false_type());
+                        MF_INTERLEAVE();
+                        if constexpr (decltype(more)::value) chain(afn, 0, acc0);
+                        fold(st[1], acc1, ct, std::false_type());
+                        MF_INTERLEAVE();
+                    };
+                    // two codeword tiles per trip: the operand registers swap roles
+                    int ct = 0;
+                    for (; ct < cn - 64; ct += 64) {
+                        step(ct, afa, afb, std::true_type());
+                        step(ct + 32, afb, afa, std::true_type());
+                    }
+                    if (ct < cn - 32) {
+                        step(ct, afa, afb, std::true_type());
+                        step(ct + 32, afb, afa, std::false_type());
                     } else {
-                    // both pixel tiles first, so the second chain of MFMAs
-                    // runs under the first tile's epilogue
-                    f32x16 acc[2];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        // the table entries are -t (t = 1, or 1/2 above 16 bits),
-                        // so acc = -t * (sum of the on bits).  For a uniform
-                        // codebook that is the key: d^2 / 2 = 1 + acc * v / t for a
-                        // unit trace.  (The zero start is an MFMA inline constant.)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[tt][i] = 0.0f;
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                            for (int s = 0; s < NSPLIT; ++s) {
-                                u32x4 bv;
-                                bv.x = pk[s][ks][4 * tt + 0]; bv.y = pk[s][ks][4 * tt + 1];
-                                bv.z = pk[s][ks][4 * tt + 2]; bv.w = pk[s][ks][4 * tt + 3];
-                                acc[tt] = mfma_tile(af[ks], bv, acc[tt]);
-                            }
-                    }
-                    // lane holds codewords ct + (i&3) + 8*(i>>2) + 4*half of
-                    // pixel (lane&31) + 32*tt in accumulator slot i.  Zero
-                    // padding rows of a uniform table are caught after the merge.
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const float before = st[tt].best;
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            if (gq == 2 && rows_left <= 16) break;   // padding rows, see above
-                            float s4[4];
-                            if constexpr (UNI) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) s4[i] = acc[tt][4 * gq + i];
-                            } else {
-                                // (1 + |c|^2) / 2 - v * sum = d^2 / 2
-                                const int nl = ct + 8 * gq + 4 * half;
-                                const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
-                                const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
-                                s4[0] = fmaf(vv.x, acc[tt][4 * gq + 0], hh.x);
-                                s4[1] = fmaf(vv.y, acc[tt][4 * gq + 1], hh.y);
-                                s4[2] = fmaf(vv.z, acc[tt][4 * gq + 2], hh.z);
-                                s4[3] = fmaf(vv.w, acc[tt][4 * gq + 3], hh.w);
-                            }
-                            top2_update4<EXCL>(st[tt], score_key(s4[0], 4 * gq + 0),
-                                         score_key(s4[1], 4 * gq + 1), score_key(s4[2], 4 * gq + 2),
-                                         score_key(s4[3], 4 * gq + 3));
-                        }
-                        st[tt].tile = st[tt].best != before ? c0 + ct : st[tt].tile;
-                    }
+                        step(ct, afa, afb, std::false_type());
                     }
                 }
             }
@@ -977,9 +1021,10 @@ decode_kernel(const DecodeArgs a)
             // EXCL: no runner-up, so the tie test below never fires
             const float ksecond = EXCL ? KEY_INIT : fmin3(from1 ? b0 : b1, s0, s1);
             const int slot = __float_as_int(kbest) & KEY_SLOT_MASK;
-            int win = (from1 ? (int)si[1] + 4 : (int)si[0]) + (slot & 3) + 8 * (slot >> 2);
-            const float best = __int_as_float(__float_as_int(kbest) & ~KEY_SLOT_MASK);
-            const float second = __int_as_float(__float_as_int(ksecond) & ~KEY_SLOT_MASK);
+            int win = (from1 ? (int)si[1] + 4 : (int)si[0]) + (TAG ? (slot & 3) + 8 * (slot >> 2) : 0);
+            const float best = TAG ? __int_as_float(__float_as_int(kbest) & ~KEY_SLOT_MASK) : kbest;
+            const float second = TAG ? __int_as_float(__float_as_int(ksecond) & ~KEY_SLOT_MASK)
+                                     : ksecond;
             // TIE_EPS is in score (v * sum) units: a uniform key is t / v times
             // that; the slot bits move a key by < 2^-19 of itself
             const float eps = (UNI ? TIE_EPS * key_scale : TIE_EPS) + fabsf(second) * 0x1p-18f;
@@ -987,34 +1032,88 @@ decode_kernel(const DecodeArgs a)
 #ifdef MF_ABL_NOF64
             double d2 = (double)best;
 #else
-            // the winner's mask and value: from LDS / a scalar for a resident
-            // uniform codebook (no dependent global gather in front of the
-            // stores), else from the table in global memory
-            uint32_t wmask;
-            double wv;
-            if (UNI && single_chunk) {
-                wmask = lds_mask[win];
-                wv = v64u;
+            double d2;
+            if constexpr (TAG) {
+                // the winner's mask and value: from LDS / a scalar for a resident
+                // uniform codebook (no dependent global gather in front of the
+                // stores), else from the table in global memory
+                uint32_t wmask;
+                double wv;
+                if (UNI && single_chunk) {
+                    wmask = lds_mask[win];
+                    wv = v64u;
+                } else {
+                    wmask = g_mask[win];
+                    wv = g_v64[win];
+                }
+                d2 = exact_d2<MAXB>(x[o], wmask, wv, B);
             } else {
-                wmask = g_mask[win];
-                wv = g_v64[win];
+                // the smallest key came from one of the 16 codewords this half
+                // of the lane pair held of the recorded tile: exact distances of
+                // those, in index order (the lowest index wins an exact tie)
+                // (a zero padding row of a uniform table has key 0 and beats the
+                // real codewords when all their sums are negative: no candidate
+                // then, and the scan below decides)
+                const int base = win;
+                const bool real = !UNI || kbest < 0.0f;
+                d2 = INFINITY;
+                win = a.N;
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int n = base + (i & 3) + 8 * (i >> 2);
+                    if (real && n < a.N) {
+                        const double e = exact_d2<MAXB>(x[o], g_mask[n], UNI ? v64u : g_v64[n], B);
+                        if (e < d2) { d2 = e; win = n; }
+                    }
+                }
             }
-            double d2 = exact_d2<MAXB>(x[o], wmask, wv, B);
 #endif
             // a zero padding row can only "win" when every real sum is <= 0
+            bool rescan = false;
 #ifdef MF_ABL_NOSCAN
             if (win >= a.N) {
 #else
             if (win >= a.N ||
                 (second - best < eps && d2 <= a.dthr * a.dthr + TIE_D2_MARGIN)) {
 #endif
-                // ambiguous and possibly within the threshold: exact scan,
-                // lowest index wins exact ties (the oracle's rule)
-                d2 = INFINITY;
-                for (int n = 0; n < a.N; ++n) {
-                    const double e = exact_d2<MAXB>(x[o], g_mask[n], g_v64[n], B);
-                    if (e < d2) { d2 = e; win = n; }
+                if constexpr (MAXB <= 16) {
+                    // (at most 16 bits: a short codebook, and the cooperative
+                    // scan below would cost this kernel registers it does not have)
+                    d2 = INFINITY;
+                    for (int n = 0; n < a.N; ++n) {
+                        const double e = exact_d2<MAXB>(x[o], g_mask[n], g_v64[n], B);
+                        if (e < d2) { d2 = e; win = n; }
+                    }
+                } else {
+                    rescan = true;
                 }
+            }
+            // ambiguous and possibly within the threshold: exact scan, lowest
+            // index wins exact ties (the oracle's rule).  Above 16 bits the wave
+            // takes its flagged pixels one at a time and spreads the N codewords of
+            // each over its 64 lanes (a lane scanning alone keeps the other 63
+            // waiting for N float64 distances: 10 % of the kernel at 10 000
+            // codewords)
+            if constexpr (MAXB > 16)
+            for (unsigned long long todo = __ballot(rescan); todo; todo &= todo - 1) {
+                const int src = __ffsll((long long)todo) - 1;
+                float xs[MAXB];
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b)
+                    xs[b] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x[o][b]), src));
+                double e_min = INFINITY;
+                int n_min = a.N;
+                for (int n = lane; n < a.N; n += 64) {        // ascending: a lane keeps its lowest index
+                    const double e = exact_d2<MAXB>(xs, g_mask[n], g_v64[n], B);
+                    if (e < e_min) { e_min = e; n_min = n; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double e2 = __shfl_xor(e_min, off);
+                    const int n2 = __shfl_xor(n_min, off);
+                    if (e2 < e_min || (e2 == e_min && n2 < n_min)) { e_min = e2; n_min = n2; }
+                }
+                if (lane == src) { d2 = e_min; win = n_min; }
             }
             const double d = sqrt_d2(d2);
 
@@ -1062,7 +1161,7 @@ decode_kernel(const DecodeArgs a)
     }
 }
 
-template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, bool EXCL>
+template <typename PIX, int R, int MAXB, int PPT, bool UNI, bool FULL, int SM>
 int launch(DecodeArgs &a, hipStream_t stream)
 {
     using HT = typename HType<PIX>::type;
@@ -1100,7 +1199,7 @@ int launch(DecodeArgs &a, hipStream_t stream)
     if (grid > nt) grid = nt;
     grid = (grid + 7) & ~int64_t(7);
 
-    auto kern = decode_kernel<PIX, R, MAXB, PPT, UNI, FULL, EXCL>;
+    auto kern = decode_kernel<PIX, R, MAXB, PPT, UNI, FULL, SM>;
     if (lds > 48 * 1024)
         MF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1118,17 +1217,30 @@ constexpr bool USE_FULL = true;
 constexpr bool USE_FULL = false;
 #endif
 
+#ifndef MF_GROUPED_MIN_N
+#define MF_GROUPED_MIN_N 3072
+#endif
+constexpr int GROUPED_MIN_N = MF_GROUPED_MIN_N;
+
 template <typename PIX, int R, int MAXB, int PPT>
 int dispatch_kind(DecodeArgs &a, hipStream_t s)
 {
     if constexpr (USE_FULL) {
         if (a.B == MAXB && a.fast_div)
-            return a.uniform ? launch<PIX, R, MAXB, PPT, true, true, false>(a, s)
-                             : launch<PIX, R, MAXB, PPT, false, true, false>(a, s);
+            return a.uniform ? launch<PIX, R, MAXB, PPT, true, true, SEARCH_TOP2>(a, s)
+                             : launch<PIX, R, MAXB, PPT, false, true, SEARCH_TOP2>(a, s);
     }
-    if (a.uniform && a.exclusive) return launch<PIX, R, MAXB, PPT, true, false, true>(a, s);
-    return a.uniform ? launch<PIX, R, MAXB, PPT, true, false, false>(a, s)
-                     : launch<PIX, R, MAXB, PPT, false, false, false>(a, s);
+    if (a.uniform && a.exclusive)
+        return launch<PIX, R, MAXB, PPT, true, false, SEARCH_EXCLUSIVE>(a, s);
+    if constexpr (MAXB == 32) {
+        // from a few thousand codewords on, a slot tag per score costs more than
+        // 16 exact distances per pixel at the end
+        if (a.N >= GROUPED_MIN_N)
+            return a.uniform ? launch<PIX, R, MAXB, PPT, true, false, SEARCH_GROUPED>(a, s)
+                             : launch<PIX, R, MAXB, PPT, false, false, SEARCH_GROUPED>(a, s);
+    }
+    return a.uniform ? launch<PIX, R, MAXB, PPT, true, false, SEARCH_TOP2>(a, s)
+                     : launch<PIX, R, MAXB, PPT, false, false, SEARCH_TOP2>(a, s);
 }
 
 template <typename PIX, int R>
@@ -1141,10 +1253,10 @@ int dispatch_bits(DecodeArgs &a, hipStream_t s)
 template <typename PIX>
 int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
 {
-#ifdef MF_DEV_BUILD   // development: only the sigma=1 u16 <=16-bit kernels, quick compile
+#ifdef MF_DEV_BUILD   // development: only the sigma=1 u16 kernels, quick compile
     if constexpr (std::is_same<PIX, uint16_t>::value)
-        if (R == 2 && a.B <= 16) return dispatch_kind<PIX, 2, 16, MF_PPT16>(a, s);
-    return mf::fail(MF_EUNSUPPORTED, "dev build: u16, R=2, B<=16 only");
+        if (R == 2) return dispatch_bits<PIX, 2>(a, s);
+    return mf::fail(MF_EUNSUPPORTED, "dev build: u16, R=2 only");
 #else
     switch (R) {
     case 0: return dispatch_bits<PIX, 0>(a, s);

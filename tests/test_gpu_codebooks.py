@@ -72,6 +72,69 @@ def test_small_image_against_oracle(name, gpu_device):
     assert rows > 0
 
 
+def _mixed_codebook(bits, words, seed):
+    """Distinct random codewords of weight 3, 4 or 5 (a non-uniform codebook:
+    the per-codeword value and half-norm tables of the kernel), sorted."""
+    rng = np.random.default_rng(seed)
+    seen = set()
+    while len(seen) < words:
+        w = int(rng.integers(3, 6))
+        seen.add(tuple(sorted(rng.choice(bits, w, replace=False))))
+    mat = np.zeros((words, bits), dtype=np.int64)
+    for i, w in enumerate(sorted(seen)):
+        mat[i, list(w)] = 1
+    return mat
+
+
+@pytest.mark.parametrize('bits,words', [(32, 4000), (27, 3100)])
+def test_mixed_weight_large_codebook_against_oracle(bits, words, gpu_device):
+    """More than 3 072 codewords of mixed weight: the untagged search of the
+    kernel (the winner is re-scored among the 16 codewords of the recorded
+    tile) on the non-uniform tables, with a codebook streamed in chunks whose
+    last tile is partly padding; negative and all-zero traces included (a
+    padding row must not win)."""
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = _mixed_codebook(bits, words, seed=bits)
+    N, B = cb.shape
+    rng = np.random.default_rng(4)
+    img = synth_stack(cb, (40, 72), 40, seed=23)
+    img[:, :6, :8] = 0                    # nothing there: every sum is zero
+    sf = rng.uniform(200, 600, B)
+    bg = rng.uniform(50, 120, B)          # dark pixels go negative
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.5176, 1, 1)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(img, dm, sf, bg, 0.5176, 1,
+                                                   1, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert (odi >= 0).sum() > 50
+    assert_distances(d, od, gap, odi)
+
+
+def test_uniform_large_codebook_dark_pixels(gpu_device):
+    """Config 5's codebook on an image whose background exceeds the signal
+    almost everywhere (negative sums: the zero padding rows of the table hold
+    the smallest key) and on empty pixels."""
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = _codebook('cfg5')
+    N, B = cb.shape
+    img = synth_stack(cb, (40, 72), 25, seed=29)
+    img[:, 20:, :] = 0
+    sf = np.full(B, 300.0)
+    bg = np.full(B, 400.0)
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.5176, 1, 1)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(img, dm, sf, bg, 0.5176, 1,
+                                                   1, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert_distances(d, od, gap, odi)
+
+
 def _tie_image(cb, rng, blocks=6, size=10):
     """uint16 [B, H, W]: flat blocks whose on-bits all carry the SAME value,
     five on-bits per block chosen so that at least two codewords are subsets
