@@ -170,9 +170,9 @@ int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
  *   min_tm   f32 [n_regions, B]  per-bit min  of trace*magnitude, or NULL
  *            (extract_refactors / _extract_backgrounds inputs; 2-D mode)
  *   n_pixels / n_regions: the counts mf_label_components produced.
- *   decoded must be 8-byte and labels 16-byte aligned (MF_EINVAL otherwise;
- *   any hipMalloc'ed or torch tensor base is): the compaction reads four
- *   barcodes / four labels per access. */
+ *   decoded and labels must be 16-byte aligned (MF_EINVAL otherwise; any
+ *   hipMalloc'ed or torch tensor base is): the run kernels read eight barcodes
+ *   per access. */
 int mf_region_table(const int16_t *decoded, const float *magnitudes,
                     const void *distances, int dist_dtype,
                     const float *traces, int64_t tr_z_stride,

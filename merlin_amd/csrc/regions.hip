@@ -700,48 +700,64 @@ region_stats(const StatsArgs a)
 // (stable: a region's runs stay in raster order), and are then expanded back
 // into the pixel list region_stats walks.
 
-// flags of the four pixels a thread owns: bit k = run start, bit 4 + k = run
-// end, bit 8 + k = region root (run start whose label is its own index);
-// lab[k] = the label of a run start.  32-bit arithmetic: the volume has fewer
-// than 2^31 pixels.
+// A thread owns RUN_PXT = 16 consecutive pixels (two 16-byte loads of the
+// barcode image; a block 4096 pixels).  Flags: bit k = run start, bit 16 + k =
+// run end, `roots` bit k = region root (a run start whose label is its own
+// index); lab[k] = the label of a run start.  32-bit arithmetic: the volume
+// has fewer than 2^31 pixels.
+constexpr int RUN_PXT = 16;
+constexpr int RUN_CHUNK = RUN_PXT * NT;
+
 __device__ __forceinline__ unsigned run_flags(const int16_t *__restrict__ dec,
                                               const int32_t *__restrict__ L, uint32_t i0,
-                                              uint32_t n, uint32_t W, int32_t (&lab)[4])
+                                              uint32_t n, uint32_t W, int32_t (&lab)[RUN_PXT],
+                                              unsigned &roots)
 {
+    roots = 0u;
     if (i0 >= n) return 0u;
-    int c[6];                       // c[0] = left neighbour, c[5] = right neighbour
-    if (i0 + 3 < n) {
-        const ushort4 v = *reinterpret_cast<const ushort4 *>(dec + i0);
-        c[1] = (int16_t)v.x; c[2] = (int16_t)v.y; c[3] = (int16_t)v.z; c[4] = (int16_t)v.w;
+    int c[RUN_PXT + 2];             // c[0] = left neighbour, c[17] = right neighbour
+    if (i0 + RUN_PXT <= n) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(dec + i0);
+        const uint4 b = *reinterpret_cast<const uint4 *>(dec + i0 + 8);
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if ((a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & 0x80008000u) == 0x80008000u)
+            return 0u;              // sixteen unassigned pixels
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            c[1 + 2 * k] = (int)(int16_t)(w[k] & 0xffffu);
+            c[2 + 2 * k] = (int)(int16_t)(w[k] >> 16);
+        }
     } else {
-        for (uint32_t k = 0; k < 4; ++k) c[1 + k] = i0 + k < n ? (int)dec[i0 + k] : -1;
+#pragma unroll
+        for (uint32_t k = 0; k < RUN_PXT; ++k) c[1 + k] = i0 + k < n ? (int)dec[i0 + k] : -1;
     }
-    if ((c[1] & c[2] & c[3] & c[4]) < 0) return 0u;          // four unassigned pixels
     // the neighbours matter only beside an assigned pixel
     c[0] = c[1] >= 0 && i0 > 0 ? (int)dec[i0 - 1] : -1;
-    c[5] = c[4] >= 0 && i0 + 4 < n ? (int)dec[i0 + 4] : -1;
+    c[RUN_PXT + 1] = c[RUN_PXT] >= 0 && i0 + RUN_PXT < n ? (int)dec[i0 + RUN_PXT] : -1;
     uint32_t x = i0 % W;
     unsigned f = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RUN_PXT; ++k) {
         if (c[1 + k] >= 0) {
-            if (x == 0 || c[k] != c[1 + k]) {
-                f |= 1u << k;
-                lab[k] = L[i0 + k];
-                if (lab[k] == (int32_t)(i0 + k)) f |= 0x100u << k;
-            }
-            if (x == W - 1 || c[2 + k] != c[1 + k]) f |= 0x10u << k;
+            if (x == 0 || c[k] != c[1 + k]) f |= 1u << k;
+            if (x == W - 1 || c[2 + k] != c[1 + k]) f |= 0x10000u << k;
         }
         if (++x == W) x = 0;
     }
+    // the labels of the run starts: all loads first, then the root test
+#pragma unroll
+    for (int k = 0; k < RUN_PXT; ++k) lab[k] = f >> k & 1u ? L[i0 + k] : -1;
+#pragma unroll
+    for (int k = 0; k < RUN_PXT; ++k)
+        if (lab[k] == (int32_t)(i0 + k)) roots |= 1u << k;
     return f;
 }
 
 // three counts per chunk packed into one 64-bit word (21 bits each)
-__device__ __forceinline__ unsigned long long pack3(unsigned f)
+__device__ __forceinline__ unsigned long long pack3(unsigned f, unsigned roots)
 {
-    return (unsigned long long)__popc(f & 0xfu) | (unsigned long long)__popc(f & 0xf0u) << 21 |
-           (unsigned long long)__popc(f & 0xf00u) << 42;
+    return (unsigned long long)__popc(f & 0xffffu) | (unsigned long long)__popc(f >> 16) << 21 |
+           (unsigned long long)__popc(roots) << 42;
 }
 
 __global__ void __launch_bounds__(NT)
@@ -749,9 +765,11 @@ run_count(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_
           int n_chunks, int32_t *__restrict__ counts)
 {
     __shared__ unsigned long long s_part[NT / 64];
-    const uint32_t i0 = blockIdx.x * (uint32_t)CHUNK + 4u * threadIdx.x;
-    int32_t lab[4];
-    unsigned long long v = pack3(run_flags(dec, L, i0, (uint32_t)n, (uint32_t)W, lab));
+    const uint32_t i0 = blockIdx.x * (uint32_t)RUN_CHUNK + (uint32_t)RUN_PXT * threadIdx.x;
+    int32_t lab[RUN_PXT];
+    unsigned roots;
+    const unsigned f = run_flags(dec, L, i0, (uint32_t)n, (uint32_t)W, lab, roots);
+    unsigned long long v = pack3(f, roots);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
@@ -778,10 +796,11 @@ run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t
          uint32_t *__restrict__ reg_key)
 {
     __shared__ unsigned long long s_wave[NT / 64];
-    const uint32_t i0 = blockIdx.x * (uint32_t)CHUNK + 4u * threadIdx.x;
-    int32_t lab[4] = {0, 0, 0, 0};
-    const unsigned f = run_flags(dec, L, i0, (uint32_t)n, (uint32_t)W, lab);
-    const unsigned long long mine = pack3(f);
+    const uint32_t i0 = blockIdx.x * (uint32_t)RUN_CHUNK + (uint32_t)RUN_PXT * threadIdx.x;
+    int32_t lab[RUN_PXT];
+    unsigned roots;
+    const unsigned f = run_flags(dec, L, i0, (uint32_t)n, (uint32_t)W, lab, roots);
+    const unsigned long long mine = pack3(f, roots);
     // exclusive prefix of the packed counts over the block's threads
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     unsigned long long inc = mine;
@@ -802,26 +821,25 @@ run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t
     uint32_t pe = (uint32_t)offsets[cs + blockIdx.x] + (uint32_t)(ex >> 21 & 0x1fffffu);
     uint32_t pr = (uint32_t)offsets[2 * cs + blockIdx.x] + (uint32_t)(ex >> 42);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int32_t p = (int32_t)(i0 + k);
+    for (int k = 0; k < RUN_PXT; ++k) {
+        const uint32_t p = i0 + k;
         if (f >> k & 1u) {
-            const bool root = f >> (8 + k) & 1u;
             if (ps < cap_runs) {
-                run_start[ps] = p;
+                run_start[ps] = (int32_t)p;
                 run_root[ps] = lab[k];
             }
             ++ps;
-            if (root) {
+            if (roots >> k & 1u) {
                 if (pr < cap_regions) {
-                    reg_root[pr] = (uint32_t)p;
-                    const uint32_t grp = conn3d ? 0u : (uint32_t)p / (uint32_t)plane_px;
+                    reg_root[pr] = p;
+                    const uint32_t grp = conn3d ? 0u : p / (uint32_t)plane_px;
                     reg_key[pr] = grp * 32768u + (uint32_t)dec[p];
                 }
                 ++pr;
             }
         }
-        if (f >> (4 + k) & 1u) {
-            if (pe < cap_runs) run_end[pe] = p;
+        if (f >> (16 + k) & 1u) {
+            if (pe < cap_runs) run_end[pe] = (int32_t)p;
             ++pe;
         }
     }
@@ -1163,7 +1181,7 @@ int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
 
     // a run has at least one pixel: n_pix bounds the number of runs
     const size_t np = (size_t)(n_pix > 0 ? n_pix : 1), nr = (size_t)(n_reg > 0 ? n_reg : 1);
-    pl.vol_chunks = (int)((vol + CHUNK - 1) / CHUNK);
+    pl.vol_chunks = (int)((vol + RUN_CHUNK - 1) / RUN_CHUNK);
     pl.run_chunks = (int)((np + CHUNK - 1) / CHUNK);
     const size_t tiles = (np + RS_TILE - 1) / RS_TILE;
 
@@ -1711,8 +1729,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
         return mf::fail(MF_EINVAL, "distance dtype %d not f32/f64", dist_dtype);
     const int64_t vol = (int64_t)Z * H * W;
     if (vol > INT32_MAX || n_pixels > vol) return mf::fail(MF_EINVAL, "bad pixel count");
-    if (reinterpret_cast<uintptr_t>(decoded) & 7)
-        return mf::fail(MF_EINVAL, "decoded must be 8-byte aligned");
+    if (reinterpret_cast<uintptr_t>(decoded) & 15)
+        return mf::fail(MF_EINVAL, "decoded must be 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(labels) & 15)
         return mf::fail(MF_EINVAL, "labels must be 16-byte aligned");
     Plan pl;
