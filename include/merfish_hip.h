@@ -35,7 +35,7 @@ extern "C" {
 #define MF_EHIP         -4   /* a HIP runtime call failed                   */
 
 #define MF_MAX_BITS     32   /* bits per codeword supported by the kernels  */
-#define MF_MAX_RADIUS    4   /* blur radius: ksize <= 9, i.e. sigma <= 2    */
+#define MF_MAX_RADIUS    6   /* blur radius: ksize <= 13, i.e. sigma <= 3   */
 #define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
 #define MF_FRAME_COLS   10   /* float64 columns of mf_region_frame          */
 #define MF_TYPED_F32_COLS 7  /* float32 columns of mf_region_frame_typed    */

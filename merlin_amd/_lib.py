@@ -16,7 +16,7 @@ MF_DTYPE_U16 = 0
 MF_DTYPE_F32 = 1
 MF_DTYPE_F64 = 2
 MF_MAX_BITS = 32
-MF_MAX_RADIUS = 4
+MF_MAX_RADIUS = 6
 MF_REC_COLS = 12
 MF_FRAME_COLS = 10
 MF_TYPED_F32_COLS = 7

@@ -1264,6 +1264,8 @@ int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
     case 2: return dispatch_bits<PIX, 2>(a, s);
     case 3: return dispatch_bits<PIX, 3>(a, s);
     case 4: return dispatch_bits<PIX, 4>(a, s);
+    case 5: return dispatch_bits<PIX, 5>(a, s);
+    case 6: return dispatch_bits<PIX, 6>(a, s);
     }
     return mf::fail(MF_EUNSUPPORTED, "blur radius %d > %d", R, MF_MAX_RADIUS);
 #endif

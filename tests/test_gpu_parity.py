@@ -269,7 +269,46 @@ def test_large_and_odd_codebooks(case, gpu_device):
     assert np.array_equal(r[:, 14:], e[:, 14:])
 
 
-@pytest.mark.parametrize('sigma', [0, 0.5, 1, 1.5, 2])
+@pytest.mark.parametrize('sigma', [2.5, 3])
+@pytest.mark.parametrize('bits', [16, 22])
+def test_wide_gaussian_u16(sigma, bits, gpu_device):
+    """lowPassSigma 2.5 and 3: ksize 11 and 13 (decoding.py:94), blur radius 5
+    and 6 -- the widest the library builds (MF_MAX_RADIUS); odd image size, so
+    edge tiles and reflected borders on every side, 16-bit and wider
+    codebooks."""
+    from conftest import synth_stack
+    from merlin_amd.decoding import PixelBasedDecoder
+    if bits == 16:
+        cb = load_golden('g2_synth192')['codebook']
+    else:
+        from merlin_amd.codebook import random_weight_codebook
+        cb = random_weight_codebook(bits, 300, 4, seed=2).get_barcodes()
+    B = cb.shape[1]
+    rng = np.random.default_rng(int(sigma * 10) + bits)
+    img = synth_stack(cb, (75, 141), 30, seed=5, amp=(500, 60000), bg=50)
+    sf = rng.uniform(200, 600, B)
+    bg = rng.uniform(0, 60, B)
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.5176, 1, sigma)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(img, dm, sf, bg, 0.5176, 1,
+                                                   sigma, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert_distances(d, od, gap, odi)
+
+
+def test_sigma_beyond_the_widest_kernel_is_refused(gpu_device):
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    img = np.zeros((16, 64, 64), dtype=np.uint16)
+    with pytest.raises(Exception, match='lowPassSigma'):
+        dec.decode_pixels(img, np.ones(16), np.zeros(16), 0.5176, 1, 3.6)
+
+
+@pytest.mark.parametrize('sigma', [0, 0.5, 1, 1.5, 2, 2.5, 3])
 def test_float_input_path(sigma, gpu_device):
     """Non-uint16 input is blurred in float32 (cv2's float path; parity with
     cv2 itself is unpinned, the oracle fixes the operation order).  Also runs
