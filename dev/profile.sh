@@ -9,7 +9,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- \
-    python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-host-pipeline --no-preprocess --no-codebooks > $out/bench_under_rocprof.json 2> $out/kt.err || exit 1
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-pipeline --no-preprocess --no-codebooks --no-config4 --no-image-output > $out/bench_under_rocprof.json 2> $out/kt.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_kernel --output-format csv \
     -d $out/fetch -o fetch -- python3 dev/run_decode.py > $out/fetch.log 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex decode_kernel --output-format csv \

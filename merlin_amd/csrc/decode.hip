@@ -396,12 +396,16 @@ decode_kernel(const DecodeArgs a)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     HT *hs0 = reinterpret_cast<HT *>(smem);                          // [buffers][GROUP][RH][TW]
-    unsigned char *lds_a = smem + HS_BYTES;                          // bf16 [chunk][MAXB]
+    // codebook chunk: f16 [chunk][MAXB], v [chunk], hn [chunk]; a codebook that
+    // does not fit has TWO such buffers (the next chunk is staged while the
+    // current one is scanned), `bstride` bytes apart
+    unsigned char *lds_a = smem + HS_BYTES;
     float *lds_v = reinterpret_cast<float *>(lds_a + (size_t)a.chunk * MAXB * 2);
     float *lds_hn = lds_v + a.chunk;
+    const uint32_t bstride = (uint32_t)a.chunk * (MAXB * 2 + 8);
     // per-bit constants, each stored twice side by side: one 8-byte read puts
     // them where the packed two-row arithmetic wants them (no register moves)
-    f32x2 *lds_sf = reinterpret_cast<f32x2 *>(lds_hn + a.chunk);     // [MAXB] scale factors
+    f32x2 *lds_sf = reinterpret_cast<f32x2 *>(lds_a + (a.chunk >= a.Npad ? 1u : 2u) * bstride);   // [MAXB] scale factors
     f32x2 *lds_bg = lds_sf + MAXB;                                   // [MAXB] backgrounds
     f32x2 *lds_rs = lds_bg + MAXB;                                   // [MAXB] RN(1 / scale)
 
@@ -437,6 +441,30 @@ decode_kernel(const DecodeArgs a)
             for (int i = tid; i < cn; i += NTHREADS) { lds_v[i] = sv[i]; lds_hn[i] = sh[i]; }
         }
     };
+    // The same chunk into the buffer at byte offset `boff`, asynchronously: loads
+    // that write LDS directly (1 KB per wave instruction, lane i's 16 bytes at
+    // base + 16 i; no registers), complete at the next s_waitcnt vmcnt(0).
+    auto stage_chunk = [&](int c0, int cn, uint32_t boff) {
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const unsigned char *ga = a.cbt + a.off_a + (size_t)c0 * MAXB * 2;
+        const int nbytes = cn * MAXB * 2;                 // a multiple of 1024
+        for (int off = wave * 1024; off < nbytes; off += NWAVES * 1024)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga + off + lane * 16),
+                                             (lptr_t)(lds_a + boff + off), 16, 0, 0);
+        if constexpr (!UNI) {
+            const unsigned char *gv = a.cbt + a.off_v + (size_t)c0 * 4;
+            const unsigned char *gh = a.cbt + a.off_hn + (size_t)c0 * 4;
+            unsigned char *lv = reinterpret_cast<unsigned char *>(lds_v) + boff;
+            unsigned char *lh = reinterpret_cast<unsigned char *>(lds_hn) + boff;
+            for (int off = wave * 256; off < cn * 4; off += NWAVES * 256)
+                if (off + lane * 4 < cn * 4) {            // cn * 4 is a multiple of 128 only
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gv + off + lane * 4), (lptr_t)(lv + off), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gh + off + lane * 4), (lptr_t)(lh + off), 4, 0, 0);
+                }
+        }
+    };
+    uint32_t cur = 0;      // byte offset of the buffer the next scan step reads
     // uniform codebook: every codeword carries the same value
     const double v64u = UNI ? g_v64[0] : 0.0;
     const uint32_t *lds_mask = reinterpret_cast<const uint32_t *>(lds_hn);
@@ -873,28 +901,29 @@ decode_kernel(const DecodeArgs a)
 #ifdef MF_ABL_NONN
             for (int c0 = 0; c0 < 0; c0 += a.chunk) {
 #else
+            // (every wave has passed the barriers of this tile's blur by now, so
+            // nobody still reads the previous tile's last chunk)
+            if (!single_chunk && o == 0) stage_chunk(0, min(a.chunk, a.Npad), cur);
             for (int c0 = 0; c0 < a.Npad; c0 += a.chunk) {
 #endif
                 const int cn = min(a.chunk, a.Npad - c0);
                 if (!single_chunk) {
-#if defined(MF_ABL_NOCHUNKSYNC)      // timing only (wrong results)
-                    if (c0 == 0 && o == 0) load_chunk(c0, cn);
-#elif defined(MF_ABL_NOCHUNKLOAD)
+                    // this chunk was staged one step ago (the first one of a tile
+                    // just above): wait for the own loads, then for everybody's --
+                    // the barrier also says that every wave has finished the
+                    // previous step, whose buffer now receives the next chunk
+                    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
                     __syncthreads();
-                    if (c0 == 0 && o == 0) load_chunk(c0, cn);
-                    __syncthreads();
-#else
-                    __syncthreads();            // previous chunk fully consumed
-                    load_chunk(c0, cn);
-                    __syncthreads();
-#endif
+                    const int n0 = c0 + a.chunk;
+                    if (n0 < a.Npad) stage_chunk(n0, min(a.chunk, a.Npad - n0), bstride - cur);
+                    else if (o + 1 < PPT) stage_chunk(0, min(a.chunk, a.Npad), bstride - cur);
                 }
                 // A operand: 8 elements of codeword (ct + lane&31), bits 16ks + 8*half ..
                 auto load_a = [&](int ct, u32x4 (&af)[KS]) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
                         af[ks] = *reinterpret_cast<const u32x4 *>(
-                            lds_a + ((size_t)(ct + (lane & 31)) * MAXB +
+                            lds_a + cur + ((size_t)(ct + (lane & 31)) * MAXB +
                                      8 * ((2 * ks + half) ^ a_swz)) * 2);
                 };
                 // the table entries are -t (t = 1, or 1/2 above 16 bits), so acc =
@@ -935,8 +964,10 @@ decode_kernel(const DecodeArgs a)
                         } else {
                             // (1 + |c|^2) / 2 - v * sum = d^2 / 2
                             const int nl = ct + 8 * gq + 4 * half;
-                            const float4 vv = *reinterpret_cast<const float4 *>(lds_v + nl);
-                            const float4 hh = *reinterpret_cast<const float4 *>(lds_hn + nl);
+                            const float4 vv = *reinterpret_cast<const float4 *>(
+                                reinterpret_cast<const unsigned char *>(lds_v + nl) + cur);
+                            const float4 hh = *reinterpret_cast<const float4 *>(
+                                reinterpret_cast<const unsigned char *>(lds_hn + nl) + cur);
                             s4[0] = fmaf(vv.x, acc[4 * gq + 0], hh.x);
                             s4[1] = fmaf(vv.y, acc[4 * gq + 1], hh.y);
                             s4[2] = fmaf(vv.z, acc[4 * gq + 2], hh.z);
@@ -1000,6 +1031,7 @@ decode_kernel(const DecodeArgs a)
                         step(ct, afa, afb, std::false_type());
                     }
                 }
+                if (!single_chunk) cur = bstride - cur;     // the other buffer holds the next chunk
             }
 
             // ---- merge lane halves, exact float64 distance, thresholds ----
@@ -1178,15 +1210,20 @@ int launch(DecodeArgs &a, hipStream_t stream)
     // (160 KB of LDS shared between them)
     const size_t budget = (size_t)160 * 1024 / (waves_per_simd(MAXB, UNI) * 4 / NWAVES);
     int chunk = (int)((budget - hs_bytes - 768) / per_word) & ~31;
+    int n_buffers = 1;
     if (chunk >= a.Npad) {
         chunk = a.Npad;
     } else {
+        // two buffers (the next chunk is staged while this one is scanned) of
         // equal chunks, each a multiple of 32 codewords
+        n_buffers = 2;
+        chunk = (int)((budget - hs_bytes - 768) / 2 / per_word) & ~31;
+        if (chunk < 32) return mf::fail(MF_EUNSUPPORTED, "no room for a codebook chunk in LDS");
         const int n_chunks = (a.Npad + chunk - 1) / chunk;
         chunk = ((a.Npad / 32 + n_chunks - 1) / n_chunks) * 32;
     }
     a.chunk = chunk;
-    size_t lds = hs_bytes + (size_t)chunk * per_word + 3 * MAXB * 2 * sizeof(float);
+    size_t lds = hs_bytes + (size_t)n_buffers * chunk * per_word + 3 * MAXB * 2 * sizeof(float);
 #ifdef MF_LDS_MIN   // development: fewer workgroups per CU (room for other streams' kernels)
     if (lds < MF_LDS_MIN) lds = MF_LDS_MIN;
 #endif
