@@ -86,6 +86,10 @@ def random_weight_codebook(bits: int, count: int, weight: int = 4,
                            seed: int = 0) -> Codebook:
     """Distinct random codewords of fixed weight, no distance guarantee
     (SURVEY 8d config 5 stress)."""
+    from math import comb
+    if not 0 < weight <= bits or count > comb(bits, weight):
+        raise ValueError('no {} distinct codewords of weight {} in {} bits'.format(
+            count, weight, bits))
     rng = np.random.default_rng(seed)
     seen = set()
     while len(seen) < count:

@@ -25,9 +25,13 @@ from merlin_amd.decoding import PixelBasedDecoder             # noqa: E402
 
 def one_case(seed, dev):
     rng = np.random.default_rng(seed)
-    kind = int(rng.integers(4))
+    kind = int(rng.integers(5))
     if kind == 0:
         cb = load_golden('g2_synth192')['codebook']
+    elif kind == 4:                       # thousands of codewords: untagged keys, streamed chunks
+        B = int(rng.choice([24, 32]))
+        N = int(rng.integers(3100, 5000))
+        cb = random_weight_codebook(B, N, int(rng.integers(4, 6)), seed=seed).get_barcodes()
     elif kind == 3:                       # mixed weights: the general (non-uniform) kernel
         B = int(rng.choice([8, 13, 16, 21, 32]))
         N = int(rng.integers(2, 120))
@@ -42,7 +46,9 @@ def one_case(seed, dev):
         N = min(int(rng.integers(1, 400)), max(1, comb(B, w) // 2))
         cb = random_weight_codebook(B, N, w, seed=seed).get_barcodes()
     N, B = cb.shape
-    H, W = int(rng.integers(6, 150)), int(rng.integers(6, 260))   # > the largest blur radius
+    H, W = int(rng.integers(8, 150)), int(rng.integers(8, 260))   # > the largest blur radius
+    if kind == 4:
+        H, W = min(H, 50), min(W, 90)     # the oracle's brute force is N x pixels
     spots = int(rng.choice([0.0, 0.005, 0.03]) * H * W)
     img = synth_stack(cb, (1, H, W), spots, seed=seed,
                       amp=(500, float(rng.choice([5000, 60000]))),
@@ -53,7 +59,7 @@ def one_case(seed, dev):
         img = img.astype(np.float32 if dtype == 'f32' else np.float64)
     sf = np.exp(rng.uniform(np.log(0.5), np.log(2e4), B))
     bg = rng.uniform(-20, 120, B) if rng.integers(2) else np.zeros(B)
-    sigma = float(rng.choice([0, 0.5, 1, 1.5, 2]))
+    sigma = float(rng.choice([0, 0.5, 1, 1.5, 2, 2.5, 3]))
     dthr = float(rng.uniform(0.2, 0.7))
     mthr = float(rng.choice([0.0, 1.0, 1.0, 3.0]))
     desc = 'seed %d kind %d B %d N %d H %d W %d %s sigma %.1f dthr %.3f mthr %.0f' % (

@@ -79,7 +79,7 @@ def one_case(seed, dev):
     params = {'crop_width': crop,
               'minimum_area': int(rng.integers(0, 5)),
               'distance_threshold': float(rng.uniform(0.3, 0.65)),
-              'lowpass_sigma': float(rng.choice([0, 0.5, 1, 1.5, 2])),
+              'lowpass_sigma': float(rng.choice([0, 0.5, 1, 1.5, 2, 2.5, 3])),
               'decode_3d': decode3d}
     tform = None
     aligner = None
