@@ -170,6 +170,9 @@ int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixels,
  *   min_tm   f32 [n_regions, B]  per-bit min  of trace*magnitude, or NULL
  *            (extract_refactors / _extract_backgrounds inputs; 2-D mode)
  *   n_pixels / n_regions: the counts mf_label_components produced.
+ *   n_codewords: the codebook's size N (every barcode in `decoded` is < N), or
+ *   0 if unknown (then 32768): it only makes the regions' sort keys dense --
+ *   planes x N <= 1024 sorts in one pass.
  *   decoded and labels must be 16-byte aligned (MF_EINVAL otherwise; any
  *   hipMalloc'ed or torch tensor base is): the run kernels read eight barcodes
  *   per access. */
@@ -178,7 +181,7 @@ int mf_region_table(const int16_t *decoded, const float *magnitudes,
                     const float *traces, int64_t tr_z_stride,
                     int64_t tr_bit_stride, int64_t tr_pix_stride,
                     const int32_t *labels,
-                    int B, int Z, int H, int W, int conn3d,
+                    int B, int n_codewords, int Z, int H, int W, int conn3d,
                     int64_t n_pixels, int64_t n_regions,
                     double *rec, float *inten, float *mean_tm, float *min_tm,
                     void *workspace, int64_t workspace_bytes, void *stream);

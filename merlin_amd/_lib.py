@@ -80,8 +80,8 @@ def lib():
     L.mf_region_workspace_bytes.argtypes = [i32, i32, i32, i64, i64]
     L.mf_region_table.restype = i32
     L.mf_region_table.argtypes = [
-        vp, vp, vp, i32, vp, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64,
-        i64, vp, vp, vp, vp, vp, i64, vp]
+        vp, vp, vp, i32, vp, i64, i64, i64, vp, i32, i32, i32, i32, i32, i32,
+        i64, i64, vp, vp, vp, vp, vp, i64, vp]
     L.mf_refactor_sums.restype = i32
     L.mf_refactor_sums.argtypes = [vp, vp, i64, i32, i32, i32, i32, f64, vp, i32,
                                    vp, vp, vp]

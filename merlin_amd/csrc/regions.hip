@@ -791,7 +791,8 @@ run_count(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_
 __global__ void __launch_bounds__(NT)
 run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t n, int W,
          int n_chunks, const int32_t *__restrict__ offsets, int64_t cap_runs, int64_t cap_regions,
-         int plane_px, int conn3d, int32_t *__restrict__ run_start, int32_t *__restrict__ run_end,
+         int plane_px, int conn3d, uint32_t key_mul, int32_t *__restrict__ run_start,
+         int32_t *__restrict__ run_end,
          int32_t *__restrict__ run_root, uint32_t *__restrict__ reg_root,
          uint32_t *__restrict__ reg_key)
 {
@@ -833,7 +834,7 @@ run_emit(const int16_t *__restrict__ dec, const int32_t *__restrict__ L, int64_t
                 if (pr < cap_regions) {
                     reg_root[pr] = p;
                     const uint32_t grp = conn3d ? 0u : p / (uint32_t)plane_px;
-                    reg_key[pr] = grp * 32768u + (uint32_t)dec[p];
+                    reg_key[pr] = grp * key_mul + (uint32_t)dec[p];
                 }
                 ++pr;
             }
@@ -1162,17 +1163,23 @@ struct Plan {
     size_t run_start, run_end, run_root, keys_a, keys_b, vals_a, vals_b, reg_root_a, reg_root_b,
         reg_key_a, reg_key_b, reg_start, aux, chunks, totals, sort_cnt, sort_totals, total;
     int vol_chunks, run_chunks;
-    int region_key_bits, rank_bits;
+    int region_key_bits, rank_bits, key_mul;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
 
-int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl)
+int make_plan(int Z, int H, int W, int64_t n_pix, int64_t n_reg, Plan &pl, int n_codewords = 0,
+              int conn3d = 0)
 {
     const int64_t vol = (int64_t)Z * H * W;
-    int zb = 0;
-    while ((1 << zb) < Z) ++zb;
-    pl.region_key_bits = 15 + zb;      // barcode < 32768
+    // region key = plane * key_mul + barcode (one group in 3-D mode); with the
+    // codebook's size known the keys are dense: 7 planes x 140 codewords sort
+    // in ONE 10-bit pass instead of two
+    pl.key_mul = n_codewords > 0 ? n_codewords : 32768;
+    const int64_t n_keys = (int64_t)(conn3d ? 1 : Z) * pl.key_mul;
+    int kb = 1;
+    while (((int64_t)1 << kb) < n_keys) ++kb;
+    pl.region_key_bits = kb;
     if (pl.region_key_bits > 30)
         return mf::fail(MF_EUNSUPPORTED, "region key needs %d bits", pl.region_key_bits);
     int rb = 1;
@@ -1714,8 +1721,8 @@ extern "C" int64_t mf_region_workspace_bytes(int Z, int H, int W, int64_t n_pixe
 extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
                                const void *distances, int dist_dtype, const float *traces,
                                int64_t tr_z_stride, int64_t tr_bit_stride,
-                               int64_t tr_pix_stride, const int32_t *labels, int B, int Z, int H,
-                               int W, int conn3d,
+                               int64_t tr_pix_stride, const int32_t *labels, int B,
+                               int n_codewords, int Z, int H, int W, int conn3d,
                                int64_t n_pixels, int64_t n_regions, double *rec, float *inten,
                                float *mean_tm, float *min_tm, void *workspace,
                                int64_t workspace_bytes, void *stream)
@@ -1725,6 +1732,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
         return mf::fail(MF_EINVAL, "null pointer argument");
     if (B < 1 || Z < 1 || H < 1 || W < 1 || n_pixels < n_regions || n_regions < 0)
         return mf::fail(MF_EINVAL, "bad sizes");
+    if (n_codewords < 0 || n_codewords > 32768)
+        return mf::fail(MF_EINVAL, "codeword count %d outside 0..32768", n_codewords);
     if (dist_dtype != MF_DTYPE_F32 && dist_dtype != MF_DTYPE_F64)
         return mf::fail(MF_EINVAL, "distance dtype %d not f32/f64", dist_dtype);
     const int64_t vol = (int64_t)Z * H * W;
@@ -1734,7 +1743,7 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     if (reinterpret_cast<uintptr_t>(labels) & 15)
         return mf::fail(MF_EINVAL, "labels must be 16-byte aligned");
     Plan pl;
-    int rc = make_plan(Z, H, W, n_pixels, n_regions, pl);
+    int rc = make_plan(Z, H, W, n_pixels, n_regions, pl, n_codewords, conn3d);
     if (rc) return rc;
     if ((int64_t)pl.total > workspace_bytes)
         return mf::fail(MF_EWORKSPACE, "workspace %lld < %lld bytes", (long long)workspace_bytes,
@@ -1767,7 +1776,8 @@ extern "C" int mf_region_table(const int16_t *decoded, const float *magnitudes,
     hipLaunchKernelGGL(chunk_scan, dim3(3), dim3(SCAN_NT), 0, s, chunks, pl.vol_chunks, totals,
                        (pl.vol_chunks + 3) & ~3);
     hipLaunchKernelGGL(run_emit, dim3(pl.vol_chunks), dim3(NT), 0, s, decoded, labels, vol, W,
-                       pl.vol_chunks, chunks, n_pixels, n_regions, H * W, conn3d, run_start, run_end,
+                       pl.vol_chunks, chunks, n_pixels, n_regions, H * W, conn3d, (uint32_t)pl.key_mul,
+                       run_start, run_end,
                        run_root, reg_root_a, reg_key_a);
     // 2. the reference's row order of the regions: (plane, barcode), label order
     //    inside (the sort is stable); every region's place goes to its root

@@ -87,6 +87,9 @@ class DecodedVolume(object):
         self.traces = traces
         self.bit_count = bit_count
         self.traces_decoded_only = False
+        # the barcodes are known to be below the codebook's size (a volume this
+        # decoder produced); False for images that came back from the caller
+        self.codes_in_codebook = True
         self._tables = {}
 
     @property
@@ -411,6 +414,7 @@ class PixelBasedDecoder(object):
             mags, tr = mags[None], tr[None]
             dist = None if dist is None else dist[None]
         vol = DecodedVolume(up(dec), mags, dist, tr, tr.shape[1])
+        vol.codes_in_codebook = False
         keep = (decodedImage, pixelMagnitudes, pixelTraces,
                 distances if distances is not None else pixelMagnitudes)
         if all(isinstance(a, np.ndarray) for a in keep):
@@ -473,8 +477,9 @@ class PixelBasedDecoder(object):
                 _lib.check(L.mf_region_table(
                     vol.decoded.data_ptr(), vol.magnitudes.data_ptr(),
                     dist.data_ptr(), ddt, tr.data_ptr(), tr.stride(0),
-                    tr.stride(1), tr.stride(3), labels.data_ptr(), B, Z, H, W,
-                    int(is3D),
+                    tr.stride(1), tr.stride(3), labels.data_ptr(), B,
+                    self._barcodeCount if vol.codes_in_codebook else 0,
+                    Z, H, W, int(is3D),
                     n_pix, n_reg, rec.data_ptr(), inten.data_ptr(),
                     _ptr(mean_tm), _ptr(min_tm), ws.data_ptr(), ws_bytes, sp))
         return RegionTable(rec, inten, mean_tm, min_tm)
