@@ -50,7 +50,20 @@
 #include <vector>
 #include "common.h"
 
-namespace {
+// One translation unit builds everything (development builds).  The shipped
+// library compiles this file once per group of blur radii (-DMF_INST_GROUP=g:
+// radii 2g and 2g + 1; group 0 also carries the host code), in parallel: the
+// kernel templates then need a named namespace, and each group instantiates
+// its own radii explicitly.
+#ifdef MF_INST_GROUP
+#define MF_DECODE_NS mf_decode
+#define MF_OWN_RADIUS(r) ((r) / 2 == MF_INST_GROUP)
+#define MF_HOST_CODE (MF_INST_GROUP == 0)
+#else
+#define MF_DECODE_NS
+#define MF_HOST_CODE 1
+#endif
+namespace MF_DECODE_NS {
 
 constexpr int TW = 64;              // tile width  = wave width
 #ifndef MF_NWAVES
@@ -1287,6 +1300,51 @@ int dispatch_bits(DecodeArgs &a, hipStream_t s)
     return dispatch_kind<PIX, R, 32, MF_PPT32>(a, s);
 }
 
+#ifdef MF_INST_GROUP
+#define MF_INST_DEF(R)                                                            \
+    template int dispatch_bits<uint16_t, R>(DecodeArgs &, hipStream_t);           \
+    template int dispatch_bits<float, R>(DecodeArgs &, hipStream_t);
+#define MF_INST_DECL(R)                                                           \
+    extern template int dispatch_bits<uint16_t, R>(DecodeArgs &, hipStream_t);    \
+    extern template int dispatch_bits<float, R>(DecodeArgs &, hipStream_t);
+#if MF_OWN_RADIUS(0)
+MF_INST_DEF(0)
+#else
+MF_INST_DECL(0)
+#endif
+#if MF_OWN_RADIUS(1)
+MF_INST_DEF(1)
+#else
+MF_INST_DECL(1)
+#endif
+#if MF_OWN_RADIUS(2)
+MF_INST_DEF(2)
+#else
+MF_INST_DECL(2)
+#endif
+#if MF_OWN_RADIUS(3)
+MF_INST_DEF(3)
+#else
+MF_INST_DECL(3)
+#endif
+#if MF_OWN_RADIUS(4)
+MF_INST_DEF(4)
+#else
+MF_INST_DECL(4)
+#endif
+#if MF_OWN_RADIUS(5)
+MF_INST_DEF(5)
+#else
+MF_INST_DECL(5)
+#endif
+#if MF_OWN_RADIUS(6)
+MF_INST_DEF(6)
+#else
+MF_INST_DECL(6)
+#endif
+#endif
+
+#if MF_HOST_CODE
 template <typename PIX>
 int dispatch_radius(int R, DecodeArgs &a, hipStream_t s)
 {
@@ -1350,7 +1408,14 @@ void table_layout(int N, int B, CbHeader &h)
     h.total = (int64_t)off;
 }
 
+#endif  // MF_HOST_CODE
+
 }  // namespace
+
+#if MF_HOST_CODE
+#ifdef MF_INST_GROUP
+using namespace mf_decode;
+#endif
 
 extern "C" int64_t mf_codebook_table_bytes(int N, int B)
 {
@@ -1584,3 +1649,5 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     if (image_dtype == MF_DTYPE_U16) return dispatch_radius<uint16_t>(Reff, a, s);
     return dispatch_radius<float>(Reff, a, s);
 }
+
+#endif  // MF_HOST_CODE
