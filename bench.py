@@ -540,6 +540,20 @@ def main():
     torch.cuda.synchronize(dev)
     k_alone_ms = e0.elapsed_time(e1) / 20
     del v
+    # what a plain device-to-device copy reaches on this part (verify
+    # the 8 TB/s figure with a memcpy probe): 1 GiB read + 1 GiB written per copy
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    copy_gbs = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
     # ALGORITHMIC bytes per launch, SURVEY 8d: 2B (u16 stack) + 2 (int16 id) + 4
     # (magnitude) + 4 (distance) = 2B + 10 = 42 B per pixel x the 29 360 128
     # pixels one launch decodes.  `roofline.achieved` / `frac` use this figure.
@@ -729,6 +743,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'algorithmic_bytes': survey_bytes,
                 'bytes_per_px': 2 * B + 10,
+                'copy_probe_GBs': copy_gbs,
                 'frac_impl_bytes': impl_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 'impl_bytes': impl_bytes, 'valu': valu,
                 'stale_counter_files': stale,

@@ -10,7 +10,7 @@ for r in rows:
         continue
     if int(r['Calls']) < fovs - 5:
         continue
-    short = re.sub(r'\(anonymous namespace\)::', '', n)
+    short = re.sub(r'\(anonymous namespace\)::|mf_decode::', '', n)
     short = re.sub(r'rocprim::ROCPRIM_\d+_NS::(detail::)?', 'rp::', short)
     per = float(r['TotalDurationNs']) / fovs / 1e3
     if 'decode_kernel' in n:

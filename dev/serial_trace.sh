@@ -13,9 +13,9 @@ tot = 0
 rows = []
 for r in csv.DictReader(open(f)):
     n = r['Name']; c = int(r['Calls']); avg = float(r['AverageNs']) / 1e3
-    lib = ('anonymous namespace)::' in n and 'at::' not in n) or 'ROCPRIM_400200' in n
+    lib = (('anonymous namespace)::' in n or 'mf_decode::' in n) and 'at::' not in n)
     if lib and c % 12 == 0:
-        rows.append((c // 12 * avg, c // 12, avg, n.replace('(anonymous namespace)::', '')[:60]))
+        rows.append((c // 12 * avg, c // 12, avg, n.replace('(anonymous namespace)::', '').replace('mf_decode::', '')[:60]))
         tot += c // 12 * avg
 for per, k, avg, n in sorted(rows, reverse=True):
     print('%7.1f us/FOV  %d x %6.1f  %s' % (per, k, avg, n))
