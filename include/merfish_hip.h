@@ -35,7 +35,9 @@ extern "C" {
 #define MF_EHIP         -4   /* a HIP runtime call failed                   */
 
 #define MF_MAX_BITS     32   /* bits per codeword supported by the kernels  */
-#define MF_MAX_RADIUS    6   /* blur radius: ksize <= 13, i.e. sigma <= 3   */
+#define MF_MAX_RADIUS    6   /* blur radius of the fused decode kernel:
+                              ksize <= 13, i.e. sigma <= 3                 */
+#define MF_LOWPASS_MAX_RADIUS 32 /* mf_lowpass_images: ksize <= 65, sigma <= 16 */
 #define MF_REC_COLS     12   /* doubles per region row, see mf_region_table */
 #define MF_FRAME_COLS   10   /* float64 columns of mf_region_frame          */
 #define MF_TYPED_F32_COLS 7  /* float32 columns of mf_region_frame_typed    */
@@ -61,9 +63,25 @@ const char *mf_last_error_string(void);
 /* cv2.GaussianBlur kernel taps (merlin/util/decoding.py:94-97): the 16.16
  * fixed-point taps OpenCV 4.x uses for CV_16U (sum == 65536) and the float32
  * taps used for float input.  Host-only helper; h_fixed / h_float hold ksize
- * entries each. */
+ * entries each; ksize odd, <= 2 * MF_LOWPASS_MAX_RADIUS + 1. */
 int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed,
                      float *h_float);
+
+/* cv2.GaussianBlur of every plane of a stack (merlin/util/decoding.py:93-97) as
+ * a pass of its own, for lowPassSigma beyond the fused kernel of
+ * mf_decode_pixels (sigma > 3): blur with this, then decode `out` with sigma =
+ * 0 -- the same bits as the fused path would give.  uint16 planes take OpenCV
+ * >= 4's exact fixed-point path, float32 planes the float32 kernel; border
+ * REFLECT_101; ksize = 2 ceil(2 sigma) + 1 <= 65.
+ *   image  [n_planes] planes of H x W (rows contiguous), plane_stride elements
+ *          apart; out: contiguous [n_planes, H, W] of the same dtype.
+ *   workspace: mf_lowpass_workspace_bytes(...) bytes of device memory. */
+int64_t mf_lowpass_workspace_bytes(int image_dtype, int64_t n_planes, int H,
+                                   int W);
+int mf_lowpass_images(const void *image, int image_dtype, int64_t n_planes,
+                      int H, int W, int64_t plane_stride, double sigma,
+                      void *out, void *workspace, int64_t workspace_bytes,
+                      void *stream);
 
 /* Codebook table (replaces PixelBasedDecoder.__init__ /
  * _calculate_normalized_barcodes' float64 matrix, decoding.py:27-44, 254-276,

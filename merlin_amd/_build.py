@@ -23,7 +23,8 @@ DECODE_GROUPS = 4
 SOURCES = [('common.cpp', 'common', [])] + \
     [('decode.hip', 'decode_g{}'.format(g), ['-DMF_INST_GROUP={}'.format(g)])
      for g in range(DECODE_GROUPS)] + \
-    [('regions.hip', 'regions', []), ('preprocess.hip', 'preprocess', [])]
+    [('regions.hip', 'regions', []), ('preprocess.hip', 'preprocess', []),
+     ('lowpass.hip', 'lowpass', [])]
 # -ffp-contract=off: the kernels reproduce numpy's unfused float arithmetic;
 # fused multiply-adds are written explicitly where they are wanted.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',

@@ -17,6 +17,7 @@ MF_DTYPE_F32 = 1
 MF_DTYPE_F64 = 2
 MF_MAX_BITS = 32
 MF_MAX_RADIUS = 6
+MF_LOWPASS_MAX_RADIUS = 32
 MF_REC_COLS = 12
 MF_FRAME_COLS = 10
 MF_TYPED_F32_COLS = 7
@@ -29,6 +30,7 @@ MF_FRAME_STATIC_MAX_ROWS = 1048576
 
 # every symbol include/merfish_hip.h declares
 EXPORTS = ('mf_version', 'mf_last_error_string', 'mf_gaussian_taps',
+           'mf_lowpass_workspace_bytes', 'mf_lowpass_images',
            'mf_codebook_table_bytes', 'mf_codebook_prepare',
            'mf_decode_pixels', 'mf_label_components',
            'mf_region_workspace_bytes', 'mf_region_table', 'mf_refactor_sums',
@@ -62,6 +64,10 @@ def lib():
     L.mf_version.argtypes = []
     L.mf_last_error_string.restype = c.c_char_p
     L.mf_last_error_string.argtypes = []
+    L.mf_lowpass_workspace_bytes.restype = i64
+    L.mf_lowpass_workspace_bytes.argtypes = [i32, i64, i32, i32]
+    L.mf_lowpass_images.restype = i32
+    L.mf_lowpass_images.argtypes = [vp, i32, i64, i32, i32, i64, f64, vp, vp, i64, vp]
     L.mf_gaussian_taps.restype = i32
     L.mf_gaussian_taps.argtypes = [i32, f64, c.POINTER(c.c_uint32),
                                    c.POINTER(c.c_float)]

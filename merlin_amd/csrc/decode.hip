@@ -1508,8 +1508,9 @@ extern "C" int mf_codebook_prepare(const double *h_codebook, int N, int B, void 
 
 extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, float *h_float)
 {
-    if (ksize < 1 || !(ksize & 1) || ksize > 2 * MF_MAX_RADIUS + 1)
-        return mf::fail(MF_EINVAL, "ksize %d must be odd and <= %d", ksize, 2 * MF_MAX_RADIUS + 1);
+    if (ksize < 1 || !(ksize & 1) || ksize > 2 * MF_LOWPASS_MAX_RADIUS + 1)
+        return mf::fail(MF_EINVAL, "ksize %d must be odd and <= %d", ksize,
+                        2 * MF_LOWPASS_MAX_RADIUS + 1);
     if (ksize == 1) {
         if (h_fixed) h_fixed[0] = 65536u;
         if (h_float) h_float[0] = 1.0f;
@@ -1518,7 +1519,7 @@ extern "C" int mf_gaussian_taps(int ksize, double sigma, uint32_t *h_fixed, floa
     // OpenCV getGaussianKernelBitExact: double-precision taps, normalised
     if (sigma <= 0) sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8;
     const double scale2x = -0.5 / (sigma * sigma);
-    double k[2 * MF_MAX_RADIUS + 1], sum = 0.0;
+    double k[2 * MF_LOWPASS_MAX_RADIUS + 1], sum = 0.0;
     for (int i = 0; i < ksize; ++i) {
         const double xx = i - (ksize - 1) * 0.5;
         k[i] = std::exp(scale2x * xx * xx);
@@ -1578,8 +1579,10 @@ extern "C" int mf_decode_pixels(const void *image, int image_dtype, int B, int Z
     const int ksize = (int)(2 * std::ceil(2 * sigma) + 1);   // decoding.py:94
     const int R = ksize / 2;
     if (R > MF_MAX_RADIUS)
-        return mf::fail(MF_EUNSUPPORTED, "lowPassSigma %g needs ksize %d > %d", sigma, ksize,
-                        2 * MF_MAX_RADIUS + 1);
+        return mf::fail(MF_EUNSUPPORTED,
+                        "lowPassSigma %g needs ksize %d > %d: blur the stack with "
+                        "mf_lowpass_images and pass sigma = 0",
+                        sigma, ksize, 2 * MF_MAX_RADIUS + 1);
     if (R > H - 1 || R > W - 1)
         return mf::fail(MF_EINVAL, "image %dx%d smaller than blur radius %d", H, W, R);
 

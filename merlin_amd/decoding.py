@@ -238,6 +238,11 @@ class PixelBasedDecoder(object):
             imageData = imageData.contiguous()
         sf = self._f32_params(scaleFactors, B, 'scaleFactors')
         bg = self._f32_params(backgrounds, B, 'backgrounds')
+        if int(2 * np.ceil(2 * lowPassSigma) + 1) // 2 > _lib.MF_MAX_RADIUS:
+            # wider than the fused kernel's blur (sigma > 3): low-pass as a
+            # pass of its own, then decode the blurred stack with sigma = 0
+            imageData = self._lowpass_device(imageData, dt, lowPassSigma)
+            lowPassSigma = 0
 
         with torch.cuda.device(dev):
             decoded = torch.empty((Z, H, W), dtype=torch.int16, device=dev)
@@ -279,6 +284,27 @@ class PixelBasedDecoder(object):
         vol.traces_decoded_only = bool(
             flags & _lib.MF_DECODE_TRACES_DECODED_ONLY)
         return vol
+
+    def _lowpass_device(self, imageData: torch.Tensor, dt: int,
+                        lowPassSigma: float) -> torch.Tensor:
+        """cv2.GaussianBlur of every (bit, z) plane of a contiguous-row stack
+        (decoding.py:93-97) through mf_lowpass_images."""
+        L = _lib.lib()
+        dev = imageData.device
+        imageData = imageData.contiguous()
+        B, Z, H, W = imageData.shape
+        with torch.cuda.device(dev):
+            out = torch.empty_like(imageData)
+            nb = _lib.check(L.mf_lowpass_workspace_bytes(dt, B * Z, H, W))
+            ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+            _lib.check(L.mf_lowpass_images(
+                imageData.data_ptr(), dt, B * Z, H, W, H * W,
+                float(lowPassSigma), out.data_ptr(), ws.data_ptr(), nb,
+                _stream_ptr(dev)))
+            cur = torch.cuda.current_stream(dev)
+            imageData.record_stream(cur)
+            ws.record_stream(cur)
+        return out
 
     def decode_pixels(self, imageData: np.ndarray,
                       scaleFactors: np.ndarray = None,

@@ -299,13 +299,56 @@ def test_wide_gaussian_u16(sigma, bits, gpu_device):
     assert_distances(d, od, gap, odi)
 
 
-def test_sigma_beyond_the_widest_kernel_is_refused(gpu_device):
+@pytest.mark.parametrize('sigma', [3.5, 5, 8])
+@pytest.mark.parametrize('dtype', ['u16', 'f32'])
+def test_sigma_beyond_the_fused_kernel(sigma, dtype, gpu_device):
+    """lowPassSigma > 3 (ksize 15, 21, 33): the stack is blurred by
+    mf_lowpass_images and decoded with sigma = 0 -- the same results as the
+    oracle's blur + decode, uint16 (exact fixed point) and float input."""
+    from conftest import synth_stack
+    from merlin_amd.decoding import PixelBasedDecoder
+    cb = load_golden('g2_synth192')['codebook']
+    rng = np.random.default_rng(int(sigma * 10))
+    img = synth_stack(cb, (61, 83), 12, seed=7, amp=(2000, 60000), bg=50)
+    ref = img
+    if dtype == 'f32':
+        img = img.astype(np.float64) + rng.uniform(0, 1, img.shape)
+        ref = img.astype(np.float32)
+    sf = rng.uniform(20, 60, 16)
+    bg = rng.uniform(0, 30, 16)
+    dm = oracle.normalized_codebook(cb)
+    dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
+    di, pm, npt, d = dec.decode_pixels(img, sf, bg, 0.65, 1, sigma)
+    odi, opm, onpt, od, gap = oracle.decode_pixels(ref, dm, sf, bg, 0.65, 1,
+                                                   sigma, return_gap=True)
+    assert np.array_equal(pm, opm)
+    assert np.array_equal(npt, onpt)
+    assert np.array_equal(di, odi)
+    assert_distances(d, od, gap, odi)
+
+
+def test_lowpass_images_arguments(gpu_device):
+    """The C-ABI refuses what it cannot do: an image smaller than the blur
+    radius (numpy's reflect padding refuses it too), sigma beyond ksize 65,
+    a short workspace; the fused entry point names the way out."""
+    import torch
+    from merlin_amd import _lib
+    L = _lib.lib()
+    img = torch.zeros((2, 8, 8), dtype=torch.uint16, device=gpu_device)
+    out = torch.empty_like(img)
+    ws = torch.empty(2 * 8 * 8 * 4, dtype=torch.uint8, device=gpu_device)
+    args = (img.data_ptr(), _lib.MF_DTYPE_U16, 2, 8, 8, 64)
+    assert L.mf_lowpass_images(*args, 5.0, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == -1
+    assert b'smaller than blur radius' in L.mf_last_error_string()
+    assert L.mf_lowpass_images(*args, 17.0, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == -2
+    assert L.mf_lowpass_images(*args, 1.0, out.data_ptr(), ws.data_ptr(), 16, None) < 0
+    assert L.mf_lowpass_images(*args, 1.0, out.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
     from merlin_amd.decoding import PixelBasedDecoder
     cb = load_golden('g2_synth192')['codebook']
     dec = PixelBasedDecoder(ArrayCodebook(cb), device=gpu_device)
-    img = np.zeros((16, 64, 64), dtype=np.uint16)
-    with pytest.raises(Exception, match='lowPassSigma'):
-        dec.decode_pixels(img, np.ones(16), np.zeros(16), 0.5176, 1, 3.6)
+    with pytest.raises(NotImplementedError, match='lowPassSigma'):
+        dec.decode_pixels(np.zeros((16, 80, 80), dtype=np.uint16), np.ones(16),
+                          np.zeros(16), 0.5176, 1, 17)
 
 
 @pytest.mark.parametrize('sigma', [0, 0.5, 1, 1.5, 2, 2.5, 3])
@@ -342,7 +385,7 @@ def test_argument_errors(gpu_device):
     with pytest.raises(ValueError):
         dec.decode_pixels(img, scaleFactors=np.ones(3))
     with pytest.raises(NotImplementedError):
-        dec.decode_pixels(img, lowPassSigma=5)           # ksize 21 > 9
+        dec.decode_pixels(img, lowPassSigma=17)          # ksize 69 > 65
     with pytest.raises(ValueError):
         dec.decode_pixels(np.zeros((16, 2, 2), dtype=np.uint16))
     bad = cb.astype(np.float64)
