@@ -89,11 +89,22 @@ __device__ __forceinline__ void lds_unite(int *lab, int a, int b)
     }
 }
 
+constexpr int CT_LINKS = 192;       // links a wave gathers before it makes them (>= 128)
+
+// the lanes of one wave exchange data through LDS: order the LDS traffic only
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ void __launch_bounds__(NT)
 ccl_tile(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int H, int W)
 {
     __shared__ __align__(16) int16_t s_code[CT_H][CT_W];
     __shared__ int s_lab[CT_H * CT_W];
+    __shared__ int2 s_links[NT / 64][CT_LINKS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * CT_W + lane;
     const int y0 = blockIdx.y * CT_H + wave * CT_ROWS;
@@ -128,22 +139,43 @@ ccl_tile(const int16_t *__restrict__ dec, int32_t *__restrict__ L, int H, int W)
         s_lab[ly * CT_W + lane] = code[r] >= 0 ? ly * CT_W + start : -1;
     }
     __syncthreads();
+    // The links of the wave's eight rows are first gathered into a list (ballot
+    // + prefix count, no atomics) and then made 64 at a time, one per lane:
+    // made row by row, each row cost the wave the latency of its slowest
+    // lane's find / atomicMin chain, eight times over.
+    int n_links = 0;                                   // wave-uniform
+    int2 *links = s_links[wave];
+    auto make_links = [&]() {
+        wave_lds_sync();
+        for (int q = lane; q < n_links; q += 64) lds_unite(s_lab, links[q].x, links[q].y);
+        wave_lds_sync();
+        n_links = 0;
+    };
+    auto append = [&](bool want, int a, int b) {
+        const unsigned long long m = __ballot(want);
+        const int cnt = __popcll(m);
+        if (n_links + cnt > CT_LINKS) make_links();
+        if (want) links[n_links + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(a, b);
+        n_links += cnt;
+    };
 #pragma unroll
     for (int r = 0; r < CT_ROWS; ++r) {
         const int ly = wave * CT_ROWS + r;
-        if (code[r] < 0 || ly == 0) continue;
+        const bool live = code[r] >= 0 && ly > 0;
         const int i = ly * CT_W + lane;
         const int c = code[r];
-        const bool n = s_code[ly - 1][lane] == c;
-        const bool nw = lane > 0 && s_code[ly - 1][lane - 1] == c;
-        const bool ne = lane < CT_W - 1 && s_code[ly - 1][lane + 1] == c;
-        if (n) {
-            if (!(cont[r] && nw)) lds_unite(s_lab, i, i - CT_W);
-        } else {
-            if (nw && !cont[r]) lds_unite(s_lab, i, i - CT_W - 1);
-            if (ne) lds_unite(s_lab, i, i - CT_W + 1);
-        }
+        const int up = live ? ly - 1 : 0;              // row 0 is never read as a link target
+        const bool n = live && s_code[up][lane] == c;
+        const bool nw = live && lane > 0 && s_code[up][lane - 1] == c;
+        const bool ne = live && lane < CT_W - 1 && s_code[up][lane + 1] == c;
+        // with N unless W and NW match (the W pixel made that link); without N,
+        // with NW unless W matches, and with NE
+        const bool link_n = n && !(cont[r] && nw);
+        const bool link_nw = !n && nw && !cont[r];
+        append(link_n || link_nw, i, link_n ? i - CT_W : i - CT_W - 1);
+        append(!n && ne, i, i - CT_W + 1);
     }
+    make_links();
     __syncthreads();
     const int base = (int)plane + blockIdx.y * CT_H * W + blockIdx.x * CT_W;
     if (wide && !(reinterpret_cast<uintptr_t>(L) & 15)) {
