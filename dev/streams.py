@@ -9,13 +9,14 @@ dev = torch.device('cuda:0')
 cb = bench.load_codebook()
 fovs = [synthetic_fov(cb.get_barcodes(), 7, 2048, 2048, 40000, 1234 + i, dev) for i in range(2)]
 sf = bench.initial_scale_factors(fovs[0]); bg = np.zeros(16)
-for name in ('three side streams', 'labelling on the table stream', 'rows on the table stream too', 'three side streams'):
+for name in ('three side streams', 'three side streams', 'labelling on the table stream',
+             'rows on the table stream too', 'three side streams'):
     task = Decode(cb, {'crop_width': 100, 'distance_threshold': 0.5167}, device=dev)
     task.reserve_memory(fovs[0].shape, expectedBarcodes=280000)
     if name != 'three side streams':
-        task._lbl = task._table_stream(dev)
+        task._label_stream = task._table_stream
     if name == 'rows on the table stream too':
-        task._side = task._table_stream(dev)
+        task._side_stream = task._table_stream
     def run(n):
         for bc, vol in task.run_fovs((fovs[i % 2] for i in range(n)), sf, bg):
             pass

@@ -120,6 +120,21 @@ def summed_pixel_histogram(local: torch.Tensor, group=None) -> np.ndarray:
     return t.cpu().numpy()
 
 
+_WORKER_STREAMS = {}
+
+
+def _worker_stream(dev, slot):
+    """HIP stream of fragment worker ``slot`` on ``dev``, created once per
+    process."""
+    import torch
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, slot)
+    if key not in _WORKER_STREAMS:
+        with torch.cuda.device(dev):
+            _WORKER_STREAMS[key] = torch.cuda.Stream(dev)
+    return _WORKER_STREAMS[key]
+
+
 class OptimizeIteration(object):
     """One iteration of the scale-factor optimisation.
 
@@ -241,9 +256,15 @@ class OptimizeIteration(object):
         dev = self._decoder._dev()
         local = threading.local()
 
+        slots = iter(range(workers))
+        slot_lock = threading.Lock()
+
         def work(k, frag, img, ready):
             if not hasattr(local, 'stream'):
-                local.stream = torch.cuda.Stream(dev)
+                # worker i of every run uses the same stream: new streams per
+                # run would pile up on the four hardware queues HIP maps them to
+                with slot_lock:
+                    local.stream = _worker_stream(dev, next(slots))
             fovIndex, zIndex = p['fov_index'][frag]
             with torch.cuda.device(dev), torch.cuda.stream(local.stream):
                 local.stream.wait_event(ready)
