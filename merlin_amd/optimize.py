@@ -158,7 +158,10 @@ class OptimizeIteration(object):
         p.setdefault('crop_width', 0)
         # fragments in flight on one GPU (worker threads, one stream each); not
         # a parameter of the reference, which runs one process per fragment
-        p.setdefault('fragment_workers', 4)
+        # two fragments in flight: with the per-barcode sums on the device a fragment is
+        # mostly GPU latency, and main + 2 worker streams stay within HIP's four
+        # hardware queues (measured 1.2 ms per fragment; 3: 1.2, 4: 1.5, 6: 1.7)
+        p.setdefault('fragment_workers', 2)
         if p['optimize_chromatic_correction']:
             raise NotImplementedError('chromatic correction is out of scope')
         if 'fov_index' in p:
