@@ -620,6 +620,30 @@ def main():
                              'H2D of FOV k+1 overlaps the kernels of FOV k'}
         del hosts
 
+    # ---- decode_3d (decode.py:129-161): the same FOVs with one 26-connected
+    # labelling of the volume and float32 distances instead of per-plane regions
+    mode3d_line = None
+    if single and not args.no_host_pipeline:
+        t3 = Decode(codebook, dict(params, decode_3d=True), device=dev)
+        for _ in t3.run_fovs((fovs[i % 2] for i in range(6)), sf, bg):
+            pass
+        torch.cuda.synchronize(dev)
+        n3 = max(8, min(args.steps, 40))
+        t1 = time.perf_counter()
+        for bc3, _ in t3.run_fovs((fovs[i % 2] for i in range(n3)), sf, bg):
+            pass
+        torch.cuda.synchronize(dev)
+        h3 = (time.perf_counter() - t1) / n3
+        mode3d_line = {'ms_per_fov': h3 * 1e3, 'Mpx_per_s': px_fov / h3 / 1e6,
+                       'fovs': n3, 'records_per_fov': len(bc3),
+                       'note': 'decode_3d=True: regions are 26-connected across the '
+                               '7 planes, distances float32; cold window (fill and '
+                               'drain inside).  The crop of decoding.py:244 compares x '
+                               'with shape[0], which is Z in 3-D mode: crop_width 100 '
+                               'keeps no record, in the reference as here; the table '
+                               'before the crop is what the time is spent on'}
+        del t3, bc3
+
     # ---- the reference's default: write_decoded_images (decode.py:47-48,
     # 165-168) -- one 352 MB float32 hyperstack per FOV leaves the GPU and goes
     # to disk.  The headline step has no output directory; this is the same
@@ -764,6 +788,8 @@ def main():
             out['host_pipeline'] = host_line
         if image_line is not None:
             out['with_image_output'] = image_line
+        if mode3d_line is not None:
+            out['decode_3d'] = mode3d_line
         if pre_line is not None:
             out['preprocess'] = pre_line
         if cfg4 is not None:
